@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the flow-matching enhancement sampler hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input: the N=5 Euler sampler (prior sample ->
+5 x [NCSN++ forward + fused Euler update]) on BASELINE.json config[1], a batch of 8 synthetic complex
+spectrograms [8,1,256,256], fp32, synthetic (deterministic) weights of the released 65.6 M-parameter
+architecture.  Inputs are resident in HBM before the timed region.  With N > 1 GPUs every rank runs its own
+batch (per-utterance data parallel, weak scaling); the only collective is the final RCCL gather of the
+enhanced spectrograms.  Rank 0 prints ONE JSON line.
+
+Metric: enhanced spectrogram-frames/sec at N=5 solver steps (frame = one STFT column of 256 bins).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+FLOP_PER_FRAME_NFE = 2.080e9          # 532.57 GFLOP / 256 frames (T=256)
+PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 (= fp32 vector peak)
+FULL_CFG = dict(nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,), image_size=256)
+
+
+def synth_state_dict(model):
+    from flowmse_amd.util import synth
+    return {n: torch.from_numpy(synth.synth_param(n, tuple(p.shape))) for n, p in model.named_parameters()}
+
+
+def cpu_baseline(sd, nsolver, frames, reps):
+    """Oracle (CPU restatement of the reference path, 'port') on the host cores: a bounded sample of the same
+    workload -- ONE utterance [1,1,256,frames], ONE Euler step (1 NFE), all host threads -- scaled to N steps."""
+    from flowmse_amd.util import synth
+    from oracle import ncsnpp_oracle as O
+    from oracle import sampler_oracle as S
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    y = torch.from_numpy(synth.synth_spectrogram(0, 1, 256, frames))
+    z = torch.from_numpy(synth.synth_noise(0, 1, 256, frames))
+    cfg = O.make_cfg()
+    times = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        S.euler_sample_net(sd, cfg, y, z, N=1)
+        times.append(time.perf_counter() - t0)
+    t_nfe = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": frames / (nsolver * t_nfe), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch-CPU fp32 restatement) 1 utterance [1,1,256,{frames}], 1 Euler step = 1 NFE, "
+                      f"median of {reps} after 1 warm-up = {t_nfe:.3f} s/NFE, scaled to N={nsolver} "
+                      f"(the path is linear in batch and steps); torch threads = {cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--nsolver", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--profile-all", action="store_true", help="per-op timing table to stderr (extra untimed pass)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from flowmse_amd.model import VFModel
+    from flowmse_amd.sampling import get_white_box_solver
+    from flowmse_amd.util import synth
+
+    model = VFModel(backbone="ncsnpp", ode="flowmatching", **FULL_CFG)
+    sd = synth_state_dict(model.dnn)
+    model.dnn.load_state_dict(sd)
+    model = model.to(dev).eval()
+
+    B, F, T, NS = args.batch, 256, args.frames, args.nsolver
+    # this rank's batch: utterance indices rank*B .. rank*B+B-1 (seeds 1234+i / 4321+i)
+    Y = torch.cat([torch.from_numpy(synth.synth_spectrogram(rank * B + i, 1, F, T)) for i in range(B)]).to(dev)
+    Z = torch.cat([torch.from_numpy(synth.synth_noise(rank * B + i, 1, F, T)) for i in range(B)]).to(dev)
+    ws_bytes = model.dnn.reserve(B, F, T)
+
+    def step():
+        sampler = get_white_box_solver("euler", model.ode, model, Y=Y, Y_prior=Y, T_rev=1.0, t_eps=0.03, N=NS, z=Z)
+        x, n = sampler()
+        return x
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        x = step()
+    barrier()
+    model.dnn.profile_begin(0)                     # HIP events around the dominant kernel, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = step()
+    if world > 1:                                  # the path's only exchange: final gather of enhanced specs
+        gathered = [torch.empty_like(torch.view_as_real(x)) for _ in range(world)] if rank == 0 else None
+        dist.gather(torch.view_as_real(x).contiguous(), gathered, dst=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = model.dnn.profile_end()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(torch.view_as_real(x)).all(), "non-finite output"
+
+    frames_total = world * args.steps * B * T
+    value = frames_total / elapsed
+    out = {
+        "metric": "enhanced spectrogram-frames/sec at N=5 solver steps",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE config[1]: batch={B} synthetic complex spectrograms [{B},1,{F},{T}] per GPU, "
+                               f"N={NS} Euler steps, NCSN++ (65.6M params, synthetic weights) fp32",
+                   "global_batch": world * B, "frames": T, "solver_steps": NS,
+                   "parallelism": f"dp{world} (per-utterance, final RCCL gather only)",
+                   "workspace_GB": round(ws_bytes / 2 ** 30, 2)},
+        "achieved_TFLOPs_whole_path": value * NS * FLOP_PER_FRAME_NFE / world / 1e12,
+    }
+    if rank == 0:
+        dom = prof.get("conv_mfma_128x128")
+        if dom and dom["ms"] > 0:
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "flowse::conv_mfma_kernel<2,2,2,2> (fp32 implicit-GEMM conv)",
+                               "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                               "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                               "flops_per_launch_avg": dom["flops"] / dom["launches"],
+                               "time_share_of_step": dom["ms"] * 1e-3 / elapsed}
+        if args.profile_all:
+            model.dnn.profile_begin(1)
+            step()
+            torch.cuda.synchronize()
+            table = model.dnn.profile_end()
+            tot = sum(v["ms"] for v in table.values())
+            print(f"# per-op GPU time, one step ({tot:.2f} ms in kernels)", file=sys.stderr)
+            for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+                tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0
+                gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0
+                print(f"# {k:44s} n={v['launches']:4d} {v['ms']:9.3f} ms {100*v['ms']/tot:5.1f}% "
+                      f"{tf:7.1f} TF/s {gbs:8.0f} GB/s", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, NS, T, args.cpu_reps)
+            out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

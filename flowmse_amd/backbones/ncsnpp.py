@@ -1,0 +1,238 @@
+"""NCSN++ vector-field backbone: the reference's constructor / call signature over the HIP library.
+
+Drop-in for ``flowmse.backbones.ncsnpp.NCSNpp`` (reference flowmse/backbones/ncsnpp.py:36-404):
+
+* same constructor keywords (``NCSNpp.__init__`` :45-67) and registry name ``"ncsnpp"`` (:36);
+* same ``state_dict`` keys / shapes / ``parameters()`` order (checked against the reference in
+  tests/test_host_logic.py), so ``load_state_dict`` of a flowmse checkpoint and the torch_ema
+  ``shadow_params`` list apply unchanged;
+* ``forward(x, time_cond)``: x complex64 ``[B,2,F,T]`` (channel 0 = x_t, channel 1 = y), time_cond float32
+  ``[B]`` -> complex64 ``[B,1,F,T]`` (:247-404).
+
+The nn.Module here is only a parameter container (PyTorch = tensor container / weight loader); every
+arithmetic operation of the forward pass runs in hand-written HIP kernels behind the C ABI
+(include/flowse_hip.h).  There is no PyTorch / CPU fallback: CPU tensors raise.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from flowmse_amd import _lib
+from .shared import BackboneRegistry
+from .structure import create_handle, handle_param_table
+
+_FIXED = dict(scale_by_sigma=True, nonlinearity="swish", resamp_with_conv=True, conditional=True, fir=True,
+              fir_kernel="song", skip_rescale=True, resblock_type="biggan", progressive="output_skip",
+              progressive_input="input_skip", progressive_combine="sum", embedding_type="fourier")
+
+
+def _set_nested(root, dotted, param):
+    """Register `param` under a dotted reference key, creating container modules on the way."""
+    parts = dotted.split(".")
+    mod = root
+    for i, p in enumerate(parts[:-1]):
+        if p.isdigit():
+            mod = mod[int(p)]
+        else:
+            if not hasattr(mod, p):
+                nxt = parts[i + 1]
+                setattr(mod, p, nn.ModuleList() if nxt.isdigit() else nn.Module())
+            mod = getattr(mod, p)
+        if isinstance(mod, nn.ModuleList) and i + 1 < len(parts) - 1 and parts[i + 1].isdigit():
+            while len(mod) <= int(parts[i + 1]):
+                mod.append(nn.Module())
+    mod.register_parameter(parts[-1], param)
+
+
+@BackboneRegistry.register("ncsnpp")
+class NCSNpp(nn.Module):
+    @staticmethod
+    def add_argparse_args(parser):
+        return parser
+
+    def __init__(self, scale_by_sigma=True, nonlinearity="swish", nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2),
+                 num_res_blocks=2, attn_resolutions=(16,), resamp_with_conv=True, conditional=True, fir=True,
+                 fir_kernel="song", skip_rescale=True, resblock_type="biggan", progressive="output_skip",
+                 progressive_input="input_skip", progressive_combine="sum", init_scale=0., fourier_scale=16,
+                 image_size=256, embedding_type="fourier", dropout=.0, **unused_kwargs):
+        super().__init__()
+        given = dict(scale_by_sigma=scale_by_sigma, nonlinearity=nonlinearity, resamp_with_conv=resamp_with_conv,
+                     conditional=conditional, fir=fir, fir_kernel=fir_kernel, skip_rescale=skip_rescale,
+                     resblock_type=str(resblock_type).lower(), progressive=str(progressive).lower(),
+                     progressive_input=str(progressive_input).lower(),
+                     progressive_combine=str(progressive_combine).lower(),
+                     embedding_type=str(embedding_type).lower())
+        for k, v in _FIXED.items():
+            # scale_by_sigma / fir_kernel / resamp_with_conv are never read by the reference forward
+            if k in ("scale_by_sigma", "fir_kernel", "resamp_with_conv"):
+                continue
+            if given[k] != v:
+                raise NotImplementedError(
+                    f"NCSNpp({k}={given[k]!r}): the HIP hot path implements the released FlowSE configuration "
+                    f"({k}={v!r}) only")
+        if dropout != 0.0:
+            raise NotImplementedError("dropout > 0 is a training feature; the sampler path is inference only")
+        self.nf = nf
+        self.ch_mult = tuple(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.attn_resolutions = tuple(attn_resolutions)
+        self.num_resolutions = len(self.ch_mult)
+        self.all_resolutions = [image_size // (2 ** i) for i in range(self.num_resolutions)]
+        self.image_size = image_size
+        self.init_scale = init_scale
+        self.fourier_scale = fourier_scale
+        self.scale_by_sigma = scale_by_sigma
+        self.conditional = conditional
+        self.skip_rescale = skip_rescale
+        self.resblock_type = given["resblock_type"]
+        self.progressive = given["progressive"]
+        self.progressive_input = given["progressive_input"]
+        self.embedding_type = given["embedding_type"]
+
+        self._handle = create_handle(dict(nf=nf, ch_mult=self.ch_mult, num_res_blocks=num_res_blocks,
+                                          attn_resolutions=self.attn_resolutions, image_size=image_size))
+        names, shapes, offsets = handle_param_table(self._handle)
+        self._param_names, self._param_shapes, self._param_offsets = names, shapes, offsets
+        self._blob_numel = int(_lib.lib.flowse_model_blob_numel(self._handle))
+        # output_layer first, then all_modules.* : the reference's registration order (ncsnpp.py:97,245)
+        self.output_layer = nn.Module()
+        self.all_modules = nn.ModuleList(
+            [nn.Module() for _ in range(_lib.lib.flowse_model_num_modules(self._handle))])
+        for name, shape in zip(names, shapes):
+            p = nn.Parameter(torch.zeros(*shape), requires_grad=not name.endswith("all_modules.0.W"))
+            _set_nested(self, name, p)
+        self.reset_parameters()
+        self._uploaded_versions = None
+        self._uploaded_device = None
+
+    # ------------------------------------------------------------------ initialisation (reference rules)
+    @torch.no_grad()
+    def reset_parameters(self):
+        """DDPM variance-scaling init as in the reference (layers.py:54-91: fan_avg, uniform; init_scale=0
+        tensors get scale 1e-10), zero biases, unit GroupNorm, W ~ N(0, fourier_scale^2)."""
+        for name, p in self.named_parameters():
+            leaf = name.split(".")[-1]
+            parent = name.split(".")[-2] if "." in name else ""
+            if name == "all_modules.0.W":
+                p.copy_(torch.randn(p.shape) * self.fourier_scale)
+            elif leaf in ("bias", "b"):
+                p.zero_()
+            elif p.dim() == 1:                                    # GroupNorm weight
+                p.fill_(1.0)
+            else:
+                scale = 1.0
+                if parent == "Conv_1" or parent == "NIN_3":
+                    scale = self.init_scale                       # layerspp.py:71,232
+                elif parent.startswith("NIN"):
+                    scale = 0.1                                   # layers.py:547
+                elif p.dim() == 4 and p.shape[0] == 4 and p.shape[-1] == 3:
+                    scale = self.init_scale                       # pyramid heads, ncsnpp.py:212,224
+                scale = 1e-10 if scale == 0 else scale
+                shape = p.shape
+                rf = 1.0 if leaf == "W" else float(np.prod(shape)) / shape[0] / shape[1]
+                fan_in, fan_out = shape[1] * rf, shape[0] * rf
+                var = scale / ((fan_in + fan_out) / 2)
+                p.copy_((torch.rand(*shape) * 2. - 1.) * np.sqrt(3 * var))
+
+    # ------------------------------------------------------------------ weights -> library
+    def _params_in_order(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n in self._param_names]
+
+    def canonical_blob(self):
+        """Flat float32 CPU tensor of all parameters in reference order / layout."""
+        with torch.no_grad():
+            return torch.cat([p.detach().to("cpu", torch.float32).reshape(-1) for p in self._params_in_order()])
+
+    def upload_weights(self, device=None):
+        """(Re)pack the current parameter values into the library's device-side layouts."""
+        if device is not None:
+            torch.cuda.set_device(device)
+        blob = self.canonical_blob().contiguous()
+        assert blob.numel() == self._blob_numel
+        _lib.check(_lib.lib.flowse_model_load_weights(self._handle, C.c_void_p(blob.data_ptr()), blob.numel()))
+        self._uploaded_versions = [p._version for p in self._params_in_order()]
+        self._uploaded_device = torch.cuda.current_device()
+
+    def _ensure_uploaded(self, device):
+        if self._uploaded_versions is None or self._uploaded_device != device.index or \
+                self._uploaded_versions != [p._version for p in self._params_in_order()]:
+            self.upload_weights(device)
+
+    # ------------------------------------------------------------------ calls
+    def _check_io(self, x, y, t):
+        if not x.is_cuda:
+            raise RuntimeError("flowmse_amd.NCSNpp runs on the MI355X HIP kernels only: move inputs to 'cuda' "
+                               "(there is no CPU fallback)")
+        if x.dtype != torch.complex64 or y.dtype != torch.complex64:
+            raise TypeError("x and y must be complex64")
+        if x.shape != y.shape or x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"expected x, y of shape [B,1,F,T], got {tuple(x.shape)} / {tuple(y.shape)}")
+        if t.shape != (x.shape[0],):
+            raise ValueError(f"t must have shape [{x.shape[0]}], got {tuple(t.shape)}")
+
+    def vf_call(self, x, t, y, mode):
+        """mode 0: dnn(cat[x,y], t); mode 1: -dnn(...) (VFModel.forward)."""
+        self._check_io(x, y, t)
+        self._ensure_uploaded(x.device)
+        x = x.contiguous()
+        y = y.contiguous()
+        t = t.to(device=x.device, dtype=torch.float32).contiguous()
+        out = torch.empty_like(x)
+        B, _, F, T = x.shape
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib.flowse_vf_forward(self._handle, _lib.ptr(x), _lib.ptr(y), _lib.ptr(t), _lib.ptr(out),
+                                                  B, F, T, mode, _lib.current_stream()))
+        return out
+
+    def forward(self, x, time_cond):
+        if x.dim() != 4 or x.shape[1] != 2:
+            raise ValueError(f"expected complex input [B,2,F,T], got {tuple(x.shape)}")
+        return self.vf_call(x[:, 0:1], time_cond, x[:, 1:2], 0)
+
+    def euler_sample(self, x, y, ts, dts):
+        """In-place N-step Euler integration on x (see flowse_euler_sample in include/flowse_hip.h)."""
+        t0 = torch.empty(x.shape[0], device=x.device)
+        self._check_io(x, y, t0)
+        if not (x.is_contiguous() and y.is_contiguous()):
+            raise ValueError("x and y must be contiguous")
+        self._ensure_uploaded(x.device)
+        N = len(ts)
+        ts_a = (C.c_float * N)(*[float(v) for v in ts])
+        dts_a = (C.c_float * N)(*[float(v) for v in dts])
+        B, _, F, T = x.shape
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib.flowse_euler_sample(self._handle, _lib.ptr(x), _lib.ptr(y), ts_a, dts_a, N, B, F, T,
+                                                    _lib.current_stream()))
+        return x
+
+    def reserve(self, B, F, T):
+        self._ensure_uploaded(torch.device("cuda", torch.cuda.current_device()))
+        nbytes = C.c_int64()
+        _lib.check(_lib.lib.flowse_model_reserve(self._handle, B, F, T, C.byref(nbytes)))
+        return int(nbytes.value)
+
+    def profile_begin(self, mode=0):
+        """Bracket launches with HIP events (0: dominant conv kernel only, 1: every op)."""
+        _lib.check(_lib.lib.flowse_profile_begin(self._handle, mode))
+
+    def profile_end(self):
+        import json
+        buf = C.create_string_buffer(1 << 20)
+        _lib.check(_lib.lib.flowse_profile_end(self._handle, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._uploaded_versions = None
+        return r
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                _lib.lib.flowse_model_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass

@@ -1,0 +1,102 @@
+// Shared declarations for the flowse HIP library (gfx950 / MI355X only).
+//
+// Internal activation layout is NHWC fp32: x[b][h][w][c] with c contiguous, so
+// the channel axis is the contiguous GEMM-K axis of the implicit-GEMM
+// convolutions and every normalisation / resampling kernel is a float4 stream
+// over channels.  h = frequency bin (F), w = STFT frame (T).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace flowse {
+
+// status codes of the C ABI (include/flowse_hip.h)
+enum { OK = 0, ERR_ARG = 1, ERR_HIP = 2, ERR_STATE = 3, ERR_SHAPE = 4 };
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define FLOWSE_HIP(call)                                                        \
+    do {                                                                        \
+        hipError_t _e = (call);                                                 \
+        if (_e != hipSuccess) return ::flowse::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define FLOWSE_LAUNCH_CHECK()                                                   \
+    do {                                                                        \
+        hipError_t _e = hipGetLastError();                                      \
+        if (_e != hipSuccess) return ::flowse::hip_fail(_e, "kernel launch", __FILE__, __LINE__); \
+    } while (0)
+
+// GroupNorm parameters resolved per (sample, channel) by gn_finalize:
+//   y = (x - mean[b][c]) * scale[b][c] + beta[c],  scale = rstd * gamma
+struct GnParams {
+    const float* mean;   // [B][C]
+    const float* scale;  // [B][C]
+    const float* beta;   // [C]
+};
+
+// ------------------------------------------------------------------ conv (implicit GEMM, MFMA fp32)
+struct ConvArgs {
+    const float* in1;   // [B][H][W][C1]
+    const float* in2;   // [B][H][W][C2] or null: channel concat [in1, in2]
+    int C1, C2;
+    const float* w;     // packed [Cout][taps][C1+C2]
+    const float* bias;  // [Cout] or null
+    const float* bias2; // per-sample bias table, element (b, co) at bias2[b*bias2_stride + co], or null
+    int bias2_stride;
+    const float* res;   // residual [B][H][W][Cout] or null (may alias out)
+    float* out;         // [B][H][W][Cout]
+    int B, H, W, Cout;
+    int taps;           // 9 (3x3, pad 1) or 1 (1x1)
+    float scale;        // out = (acc + bias + bias2 + res) * scale
+};
+int launch_conv(const ConvArgs& a, hipStream_t s);
+
+// direct conv for 4 input channels (input layer, Combine): VALU, HBM-bound
+int launch_conv_cin4(const ConvArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ GroupNorm
+// stats over (C/G channels) x H x W for a (possibly concatenated) NHWC tensor
+int gn_partial_blocks(int HW, int C);
+int launch_gn_stats(const float* in1, int C1, const float* in2, int C2, int B, int HW,
+                    float* partial /*[B][nblk][C][2]*/, int nblk, hipStream_t s);
+int launch_gn_finalize(const float* partial, int nblk, int B, int HW, int C, int G,
+                       const float* gamma, float eps, float* mean /*[B][C]*/, float* scale /*[B][C]*/,
+                       hipStream_t s);
+int launch_gn_apply(const float* in1, int C1, const float* in2, int C2, int B, int HW,
+                    GnParams gn, int silu, float* out, hipStream_t s);
+
+// ------------------------------------------------------------------ FIR resampling ([1,3,3,1] x [1,3,3,1] / 64)
+// down: out[B][H/2][W/2][C]; up: out[B][2H][2W][C] (gain 4).  Optional fused GN(+SiLU) on the input
+// (gn.mean == null -> raw), optional elementwise `add` tensor (same shape as out) summed into the result.
+int launch_fir_down(const float* in, int B, int H, int W, int C, GnParams gn, int silu, float* out,
+                    hipStream_t s);
+int launch_fir_up(const float* in, int B, int H, int W, int C, GnParams gn, int silu, const float* add,
+                  float* out, hipStream_t s);
+// generic NCHW upfirdn2d (drop-in for the reference's op/upfirdn2d ABI), kernel up to 8x8
+int launch_upfirdn2d_nchw(const float* in, const float* kernel, int planes, int in_h, int in_w, int kh,
+                          int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                          int pad_y0, int pad_y1, float* out, int out_h, int out_w, hipStream_t s);
+
+// ------------------------------------------------------------------ attention
+// qkv: [B][L][3C] (q | k | v per token), out: [B][L][C]; softmax(q k^T * C^-1/2) v, single head
+int launch_attention(const float* qkv, int B, int L, int C, float* out, hipStream_t s);
+
+// ------------------------------------------------------------------ small ops
+int launch_pack_input(const float* x_c64, const float* y_c64, int B, int F, int T, float* out4, hipStream_t s);
+// GaussianFourierProjection(log t): out[b][0:E] = sin, out[b][E:2E] = cos
+int launch_gfp(const float* t, const float* Wf, int B, int E, float* out, hipStream_t s);
+// out[b][r] = act(sum_k W[r][k] in[b][k] + bias[r]); act: 0 none, 1 SiLU
+int launch_linear(const float* in, int B, int K, const float* W, const float* bias, int R, int act,
+                  float* out, int out_stride, hipStream_t s);
+// head: v = Wout (pyr / t[b]) + bout  (1x1 conv 4 -> 2, complex pack)
+//   mode 0: out = v            (NCSNpp.forward)
+//   mode 1: out = -v           (VFModel.forward)
+//   mode 2: out = x + dt * v   (Euler update  x + VF * (-dt), VF = -v); out may alias x
+int launch_head(const float* pyr4, const float* t, const float* Wout /*[2][4]*/, const float* bout /*[2]*/,
+                int B, int F, int T, int mode, const float* x_c64, float dt, float* out_c64, hipStream_t s);
+// out = y + sigma * z   (complex64 as float pairs)
+int launch_axpy(const float* y, const float* z, float sigma, int64_t n, float* out, hipStream_t s);
+
+}  // namespace flowse

@@ -1,0 +1,143 @@
+// Small HBM-bound / latency-bound kernels around the network body.
+#include "common.h"
+
+namespace flowse {
+
+static int grid_for(int64_t total) {
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Feature pack: complex x, y [B,1,F,T] (interleaved re,im) -> real NHWC [B][F][T][4] = (x.re, x.im, y.re, y.im).
+// Replaces (reference): torch.cat([x, y], 1) of VFModel.forward (flowmse/model.py:166) + the real/imag
+// split of NCSNpp.forward (flowmse/backbones/ncsnpp.py:252-254).
+__global__ __launch_bounds__(256) void pack_input_kernel(const float2* __restrict__ x, const float2* __restrict__ y,
+                                                         int64_t n, float4* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float2 a = x[i], b = y[i];
+        out[i] = make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+
+int launch_pack_input(const float* x, const float* y, int B, int F, int T, float* out4, hipStream_t s) {
+    const int64_t n = (int64_t)B * F * T;
+    hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(n)), dim3(256), 0, s, reinterpret_cast<const float2*>(x),
+                       reinterpret_cast<const float2*>(y), n, reinterpret_cast<float4*>(out4));
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Gaussian Fourier time embedding.  Replaces (reference): torch.log(t) (ncsnpp.py:259) +
+// GaussianFourierProjection.forward (layerspp.py:39-41): x_proj = ((log t * W) * 2) * pi in fp32,
+// out = [sin(x_proj), cos(x_proj)].  log / sin / cos are evaluated in fp64 from the fp32 operands and
+// rounded once, so the result is the correctly rounded fp32 value of the reference's expression.
+__global__ void gfp_kernel(const float* __restrict__ t, const float* __restrict__ Wf, int E, float* __restrict__ out) {
+    const int b = blockIdx.x;
+    const float lt = (float)log((double)t[b]);
+    for (int j = threadIdx.x; j < E; j += blockDim.x) {
+        const float p = __fmul_rn(__fmul_rn(__fmul_rn(lt, Wf[j]), 2.0f), 3.14159274101257324f);
+        out[(int64_t)b * 2 * E + j] = (float)sin((double)p);
+        out[(int64_t)b * 2 * E + E + j] = (float)cos((double)p);
+    }
+}
+
+int launch_gfp(const float* t, const float* Wf, int B, int E, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(gfp_kernel, dim3(B), dim3(128), 0, s, t, Wf, E, out);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row-parallel linear layer for the time-embedding MLP (ncsnpp.py:262-267) and the 49 per-block
+// Dense_0(SiLU(temb)) projections (layerspp.py:262-263), all of which depend only on t: they are evaluated
+// once per solver step into one bias table that the Conv_0 epilogues read.
+//   out[b*out_stride + r] = act( sum_k W[r][k] * in[b][k] + bias[r] ),   one wave per row r, all b.
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ in, int B, int K,
+                                                     const float* __restrict__ W, const float* __restrict__ bias,
+                                                     int R, int act, float* __restrict__ out, int out_stride) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const float* wr = W + (int64_t)r * K;
+    for (int b = 0; b < B; ++b) {
+        const float* x = in + (int64_t)b * K;
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) acc = fmaf(wr[k], x[k], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) {
+            float v = acc + (bias ? bias[r] : 0.f);
+            if (act) v = silu_f(v);
+            out[(int64_t)b * out_stride + r] = v;
+        }
+    }
+}
+
+int launch_linear(const float* in, int B, int K, const float* W, const float* bias, int R, int act, float* out,
+                  int out_stride, hipStream_t s) {
+    hipLaunchKernelGGL(linear_kernel, dim3((R + 3) / 4), dim3(256), 0, s, in, B, K, W, bias, R, act, out, out_stride);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Output head, fused with the solver update.  Replaces (reference): h / t (ncsnpp.py:398), output_layer
+// conv1x1 4->2 (:401), permute + view_as_complex (:402-403), the negation of VFModel.forward (model.py:169)
+// and EulerODEsolver.update_fn  x + VF * (-stepsize)  (sampling/odesolvers.py:42-47).
+__global__ __launch_bounds__(256) void head_kernel(const float4* __restrict__ pyr, const float* __restrict__ t,
+                                                   const float* __restrict__ Wout, const float* __restrict__ bout,
+                                                   int64_t n, int64_t per_sample, int mode,
+                                                   const float2* __restrict__ x, float dt, float2* __restrict__ out) {
+    const float w00 = Wout[0], w01 = Wout[1], w02 = Wout[2], w03 = Wout[3];
+    const float w10 = Wout[4], w11 = Wout[5], w12 = Wout[6], w13 = Wout[7];
+    const float b0 = bout[0], b1 = bout[1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float tb = t[i / per_sample];
+        float4 p = pyr[i];
+        p.x = p.x / tb; p.y = p.y / tb; p.z = p.z / tb; p.w = p.w / tb;
+        float re = fmaf(w03, p.w, fmaf(w02, p.z, fmaf(w01, p.y, w00 * p.x))) + b0;
+        float im = fmaf(w13, p.w, fmaf(w12, p.z, fmaf(w11, p.y, w10 * p.x))) + b1;
+        if (mode == 1) {
+            re = -re;
+            im = -im;
+        } else if (mode == 2) {
+            const float2 xv = x[i];
+            re = xv.x + __fmul_rn(re, dt);
+            im = xv.y + __fmul_rn(im, dt);
+        }
+        out[i] = make_float2(re, im);
+    }
+}
+
+int launch_head(const float* pyr4, const float* t, const float* Wout, const float* bout, int B, int F, int T, int mode,
+                const float* x, float dt, float* out, hipStream_t s) {
+    const int64_t n = (int64_t)B * F * T;
+    hipLaunchKernelGGL(head_kernel, dim3(grid_for(n)), dim3(256), 0, s, reinterpret_cast<const float4*>(pyr4), t, Wout,
+                       bout, n, (int64_t)F * T, mode, reinterpret_cast<const float2*>(x), dt,
+                       reinterpret_cast<float2*>(out));
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Prior sample x_T = y + sigma(1) * z.  Replaces (reference): FLOWMATCHING.prior_sampling (flowmse/odes.py:93-100)
+// with the noise z supplied by the caller.
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ y, const float* __restrict__ z,
+                                                   float sigma, int64_t n, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = y[i] + __fmul_rn(z[i], sigma);
+}
+
+int launch_axpy(const float* y, const float* z, float sigma, int64_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, z, sigma, n, out);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+}  // namespace flowse

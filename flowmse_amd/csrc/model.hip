@@ -1,0 +1,1107 @@
+// Model handle: NCSN++ module list, parameter table, weight packing and the static launch plan.
+//
+// Mirrors (reference) NCSNpp.__init__ (flowmse/backbones/ncsnpp.py:97-245: module order = parameter order)
+// and NCSNpp.forward (:247-404: the order the modules are consumed in).  The forward pass is "traced" once per
+// input shape into a flat list of kernel launches over an arena-planned activation workspace: no allocation,
+// no host synchronisation and no shape logic inside the N-step solver loop.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/flowse_hip.h"
+#include "common.h"
+
+namespace flowse {
+
+// ------------------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------- structure
+enum ModKind { M_GFP, M_LINEAR, M_CONV3, M_RESBLOCK, M_ATTN, M_COMBINE, M_GN };
+
+struct ParamInfo {
+    std::string name;
+    int ndim;
+    int64_t shape[4];
+    int64_t offset, numel;
+};
+
+struct Module {
+    ModKind kind;
+    int in_ch = 0, out_ch = 0;
+    bool up = false, down = false, shortcut = false;
+    int p0 = 0;            // index of the module's first parameter
+    // offsets (floats) into the native device weight blob
+    int64_t w_gn0_g = -1, w_gn0_b = -1, w_gn1_g = -1, w_gn1_b = -1;
+    int64_t w_c0 = -1, w_c1 = -1, w_c1_b = -1, w_c2 = -1, w_c2_b = -1;
+    int64_t w_a = -1, w_a_b = -1;      // generic weight / bias (linear, conv3, combine, gfp, gn gamma/beta)
+    int64_t w_qkv = -1, w_qkv_b = -1, w_o = -1, w_o_b = -1;
+    int dense_row0 = -1;               // first row of this block in the stacked Dense_0 table
+};
+
+struct Tn {
+    size_t off = 0;
+    int B = 0, H = 0, W = 0, C = 0;
+    size_t bytes() const { return (size_t)B * H * W * C * sizeof(float); }
+    bool valid() const { return B > 0; }
+};
+
+class Arena {
+   public:
+    size_t alloc(size_t n) {
+        n = (n + 255) & ~(size_t)255;
+        for (size_t i = 0; i < free_.size(); ++i) {
+            if (free_[i].second >= n) {
+                const size_t off = free_[i].first;
+                if (free_[i].second == n) free_.erase(free_.begin() + i);
+                else { free_[i].first += n; free_[i].second -= n; }
+                live_[off] = n;
+                return off;
+            }
+        }
+        // extend (merge with a trailing free block if it touches the end)
+        size_t off = end_;
+        if (!free_.empty() && free_.back().first + free_.back().second == end_) {
+            off = free_.back().first;
+            free_.pop_back();
+        }
+        end_ = off + n;
+        if (end_ > peak_) peak_ = end_;
+        live_[off] = n;
+        return off;
+    }
+    void release(size_t off) {
+        auto it = live_.find(off);
+        if (it == live_.end()) return;
+        const size_t n = it->second;
+        live_.erase(it);
+        size_t i = 0;
+        while (i < free_.size() && free_[i].first < off) ++i;
+        free_.insert(free_.begin() + i, std::make_pair(off, n));
+        if (i + 1 < free_.size() && free_[i].first + free_[i].second == free_[i + 1].first) {
+            free_[i].second += free_[i + 1].second;
+            free_.erase(free_.begin() + i + 1);
+        }
+        if (i > 0 && free_[i - 1].first + free_[i - 1].second == free_[i].first) {
+            free_[i - 1].second += free_[i].second;
+            free_.erase(free_.begin() + i);
+        }
+    }
+    size_t peak() const { return peak_; }
+
+   private:
+    std::vector<std::pair<size_t, size_t>> free_;   // sorted by offset
+    std::map<size_t, size_t> live_;
+    size_t end_ = 0, peak_ = 0;
+};
+
+struct CallState {            // per-call dynamic arguments read by the plan's closures
+    const float* x = nullptr;
+    const float* y = nullptr;
+    const float* t = nullptr;
+    float* out = nullptr;
+    int mode = 0;
+    float dt = 0.f;
+};
+
+struct Plan {
+    int B = 0, F = 0, T = 0;
+    size_t ws_bytes = 0;
+    std::vector<std::function<int(hipStream_t)>> ops;
+    std::vector<std::string> labels;
+    std::vector<double> flops, bytes;      // algorithmic work / HBM traffic of each launch
+    std::vector<char> dominant;            // 1 = launches conv_mfma_kernel<2,2,2,2> (the dominant kernel)
+};
+
+struct ProfAcc {
+    int64_t launches = 0;
+    double ms = 0.0, flops = 0.0, bytes = 0.0;
+};
+
+}  // namespace flowse
+
+using namespace flowse;
+
+struct flowse_model {
+    flowse_config cfg;
+    std::vector<Module> mods;
+    std::vector<ParamInfo> params;
+    int64_t blob_numel = 0;
+    int out_w_p = 0;                       // parameter index of output_layer.weight
+    int temb_dim = 0, dense_rows = 0;
+    int64_t w_dense = -1, w_dense_b = -1;  // stacked Dense_0 (+ folded Conv_0.bias)
+    int64_t w_out = -1, w_out_b = -1;
+    // device state
+    float* d_w = nullptr;                  // native weight blob
+    int64_t d_w_numel = 0;
+    char* d_ws = nullptr;                  // activation workspace
+    size_t d_ws_bytes = 0;
+    float* d_ts = nullptr;                 // [N][B] solver times
+    size_t d_ts_floats = 0;
+    std::map<std::tuple<int, int, int>, Plan> plans;
+    CallState call;
+    // optional in-library profiler (flowse_profile_begin / _end): HIP events around selected launches
+    int prof_mode = -1;                    // -1 off, 0 dominant kernel only, 1 every op
+    std::vector<hipEvent_t> prof_pool;     // reusable events
+    size_t prof_used = 0;
+    struct Pending { int label; hipEvent_t a, b; double flops, bytes; };
+    std::vector<Pending> prof_pending;
+    std::vector<std::string> prof_labels;
+    std::map<std::string, int> prof_label_ix;
+
+    float* W(int64_t off) const { return d_w + off; }
+    float* A(size_t off) const { return reinterpret_cast<float*>(d_ws + off); }
+};
+
+namespace flowse {
+
+static bool in_list(const int32_t* v, int n, int x) {
+    for (int i = 0; i < n; ++i)
+        if (v[i] == x) return true;
+    return false;
+}
+
+// ---- parameter table helpers
+static void add_param(flowse_model* m, const std::string& name, std::initializer_list<int64_t> shape) {
+    ParamInfo p;
+    p.name = name;
+    p.ndim = (int)shape.size();
+    p.numel = 1;
+    int i = 0;
+    for (int64_t s : shape) {
+        p.shape[i++] = s;
+        p.numel *= s;
+    }
+    for (; i < 4; ++i) p.shape[i] = 1;
+    p.offset = m->blob_numel;
+    m->blob_numel += p.numel;
+    m->params.push_back(p);
+}
+
+static void add_module(flowse_model* m, Module mod) {
+    const int idx = (int)m->mods.size();
+    const std::string pre = "all_modules." + std::to_string(idx) + ".";
+    mod.p0 = (int)m->params.size();
+    const int64_t ci = mod.in_ch, co = mod.out_ch, td = m->temb_dim;
+    switch (mod.kind) {
+        case M_GFP:
+            add_param(m, pre + "W", {co});
+            break;
+        case M_LINEAR:
+            add_param(m, pre + "weight", {co, ci});
+            add_param(m, pre + "bias", {co});
+            break;
+        case M_CONV3:
+            add_param(m, pre + "weight", {co, ci, 3, 3});
+            add_param(m, pre + "bias", {co});
+            break;
+        case M_GN:
+            add_param(m, pre + "weight", {co});
+            add_param(m, pre + "bias", {co});
+            break;
+        case M_COMBINE:
+            add_param(m, pre + "Conv_0.weight", {co, ci, 1, 1});
+            add_param(m, pre + "Conv_0.bias", {co});
+            break;
+        case M_RESBLOCK:
+            add_param(m, pre + "GroupNorm_0.weight", {ci});
+            add_param(m, pre + "GroupNorm_0.bias", {ci});
+            add_param(m, pre + "Conv_0.weight", {co, ci, 3, 3});
+            add_param(m, pre + "Conv_0.bias", {co});
+            add_param(m, pre + "Dense_0.weight", {co, td});
+            add_param(m, pre + "Dense_0.bias", {co});
+            add_param(m, pre + "GroupNorm_1.weight", {co});
+            add_param(m, pre + "GroupNorm_1.bias", {co});
+            add_param(m, pre + "Conv_1.weight", {co, co, 3, 3});
+            add_param(m, pre + "Conv_1.bias", {co});
+            if (mod.shortcut) {
+                add_param(m, pre + "Conv_2.weight", {co, ci, 1, 1});
+                add_param(m, pre + "Conv_2.bias", {co});
+            }
+            break;
+        case M_ATTN:
+            add_param(m, pre + "GroupNorm_0.weight", {co});
+            add_param(m, pre + "GroupNorm_0.bias", {co});
+            for (int k = 0; k < 4; ++k) {
+                add_param(m, pre + "NIN_" + std::to_string(k) + ".W", {co, co});
+                add_param(m, pre + "NIN_" + std::to_string(k) + ".b", {co});
+            }
+            break;
+    }
+    m->mods.push_back(mod);
+}
+
+static Module resblock(int in_ch, int out_ch, bool up = false, bool down = false) {
+    Module r;
+    r.kind = M_RESBLOCK;
+    r.in_ch = in_ch;
+    r.out_ch = out_ch;
+    r.up = up;
+    r.down = down;
+    r.shortcut = (in_ch != out_ch) || up || down;     // layerspp.py:234-235
+    return r;
+}
+static Module simple(ModKind k, int in_ch, int out_ch) {
+    Module r;
+    r.kind = k;
+    r.in_ch = in_ch;
+    r.out_ch = out_ch;
+    return r;
+}
+
+// NCSNpp.__init__, ncsnpp.py:97-245
+static int build_structure(flowse_model* m) {
+    const flowse_config& c = m->cfg;
+    if (c.nf < 4 || (c.nf & 3) || c.num_levels < 1 || c.num_levels > FLOWSE_MAX_LEVELS || c.num_res_blocks < 1 ||
+        c.num_attn < 0 || c.num_attn > FLOWSE_MAX_ATTN || c.image_size < (1 << (c.num_levels - 1))) {
+        set_error("invalid config: nf=%d levels=%d res_blocks=%d attn=%d image_size=%d", c.nf, c.num_levels,
+                  c.num_res_blocks, c.num_attn, c.image_size);
+        return ERR_ARG;
+    }
+    for (int i = 0; i < c.num_levels; ++i)
+        if (c.ch_mult[i] < 1) {
+            set_error("invalid ch_mult[%d]=%d", i, c.ch_mult[i]);
+            return ERR_ARG;
+        }
+    const int nf = c.nf, L = c.num_levels;
+    m->temb_dim = 4 * nf;
+    // output_layer is registered before all_modules (ncsnpp.py:97) -> first in parameters()
+    m->out_w_p = (int)m->params.size();
+    add_param(m, "output_layer.weight", {2, 4, 1, 1});
+    add_param(m, "output_layer.bias", {2});
+
+    add_module(m, simple(M_GFP, 0, nf));
+    add_module(m, simple(M_LINEAR, 2 * nf, 4 * nf));
+    add_module(m, simple(M_LINEAR, 4 * nf, 4 * nf));
+    add_module(m, simple(M_CONV3, 4, nf));
+    std::vector<int> hs_c{nf};
+    int in_ch = nf;
+    for (int lv = 0; lv < L; ++lv) {
+        const int res = c.image_size >> lv;
+        for (int b = 0; b < c.num_res_blocks; ++b) {
+            const int out_ch = nf * c.ch_mult[lv];
+            add_module(m, resblock(in_ch, out_ch));
+            in_ch = out_ch;
+            if (in_list(c.attn_resolutions, c.num_attn, res)) add_module(m, simple(M_ATTN, in_ch, in_ch));
+            hs_c.push_back(in_ch);
+        }
+        if (lv != L - 1) {
+            add_module(m, resblock(in_ch, in_ch, false, true));
+            add_module(m, simple(M_COMBINE, 4, in_ch));
+            hs_c.push_back(in_ch);
+        }
+    }
+    in_ch = hs_c.back();
+    add_module(m, resblock(in_ch, in_ch));
+    add_module(m, simple(M_ATTN, in_ch, in_ch));
+    add_module(m, resblock(in_ch, in_ch));
+    for (int lv = L - 1; lv >= 0; --lv) {
+        const int res = c.image_size >> lv;
+        for (int b = 0; b < c.num_res_blocks + 1; ++b) {
+            const int out_ch = nf * c.ch_mult[lv];
+            add_module(m, resblock(in_ch + hs_c.back(), out_ch));
+            hs_c.pop_back();
+            in_ch = out_ch;
+        }
+        if (in_list(c.attn_resolutions, c.num_attn, res)) add_module(m, simple(M_ATTN, in_ch, in_ch));
+        add_module(m, simple(M_GN, in_ch, in_ch));
+        add_module(m, simple(M_CONV3, in_ch, 4));
+        if (lv != 0) add_module(m, resblock(in_ch, in_ch, true, false));
+    }
+    if (!hs_c.empty()) {
+        set_error("internal: skip stack not empty");
+        return ERR_STATE;
+    }
+    return OK;
+}
+
+// ------------------------------------------------------------------------------------------- weight packing
+struct Packer {
+    std::vector<float> host;
+    int64_t put(int64_t n) {
+        const int64_t off = ((int64_t)host.size() + 63) & ~(int64_t)63;
+        host.resize(off + n, 0.f);
+        return off;
+    }
+};
+
+// conv weight [Cout][Cin][kh][kw] -> [Cout][kh*kw][Cin]
+static int64_t pack_conv(Packer& pk, const float* src, int Cout, int Cin, int taps) {
+    const int64_t off = pk.put((int64_t)Cout * taps * Cin);
+    float* dst = pk.host.data() + off;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < taps; ++t)
+                dst[((int64_t)co * taps + t) * Cin + ci] = src[((int64_t)co * Cin + ci) * taps + t];
+    return off;
+}
+static int64_t pack_copy(Packer& pk, const float* src, int64_t n) {
+    const int64_t off = pk.put(n);
+    memcpy(pk.host.data() + off, src, n * sizeof(float));
+    return off;
+}
+
+static int pack_weights(flowse_model* m, const float* blob, Packer& pk) {
+    auto P = [&](int idx) { return blob + m->params[idx].offset; };
+    // count Dense_0 rows
+    int rows = 0;
+    for (auto& mod : m->mods)
+        if (mod.kind == M_RESBLOCK) {
+            mod.dense_row0 = rows;
+            rows += mod.out_ch;
+        }
+    m->dense_rows = rows;
+    const int td = m->temb_dim;
+    m->w_dense = pk.put((int64_t)rows * td);
+    m->w_dense_b = pk.put(rows);
+    m->w_out = pack_copy(pk, P(m->out_w_p), 8);
+    m->w_out_b = pack_copy(pk, P(m->out_w_p + 1), 2);
+    for (auto& mod : m->mods) {
+        const int p = mod.p0, ci = mod.in_ch, co = mod.out_ch;
+        switch (mod.kind) {
+            case M_GFP:
+                mod.w_a = pack_copy(pk, P(p), co);
+                break;
+            case M_LINEAR:
+                mod.w_a = pack_copy(pk, P(p), (int64_t)co * ci);
+                mod.w_a_b = pack_copy(pk, P(p + 1), co);
+                break;
+            case M_CONV3:
+                mod.w_a = pack_conv(pk, P(p), co, ci, 9);
+                mod.w_a_b = pack_copy(pk, P(p + 1), co);
+                break;
+            case M_GN:
+                mod.w_a = pack_copy(pk, P(p), co);
+                mod.w_a_b = pack_copy(pk, P(p + 1), co);
+                break;
+            case M_COMBINE:
+                mod.w_a = pack_conv(pk, P(p), co, ci, 1);
+                mod.w_a_b = pack_copy(pk, P(p + 1), co);
+                break;
+            case M_RESBLOCK: {
+                mod.w_gn0_g = pack_copy(pk, P(p), ci);
+                mod.w_gn0_b = pack_copy(pk, P(p + 1), ci);
+                mod.w_c0 = pack_conv(pk, P(p + 2), co, ci, 9);
+                // Dense_0 rows into the stacked table; Conv_0.bias folded into the table's bias
+                memcpy(pk.host.data() + m->w_dense + (int64_t)mod.dense_row0 * td, P(p + 4),
+                       (size_t)co * td * sizeof(float));
+                for (int r = 0; r < co; ++r)
+                    pk.host[m->w_dense_b + mod.dense_row0 + r] = P(p + 5)[r] + P(p + 3)[r];
+                mod.w_gn1_g = pack_copy(pk, P(p + 6), co);
+                mod.w_gn1_b = pack_copy(pk, P(p + 7), co);
+                mod.w_c1 = pack_conv(pk, P(p + 8), co, co, 9);
+                mod.w_c1_b = pack_copy(pk, P(p + 9), co);
+                if (mod.shortcut) {
+                    mod.w_c2 = pack_conv(pk, P(p + 10), co, ci, 1);
+                    mod.w_c2_b = pack_copy(pk, P(p + 11), co);
+                }
+                break;
+            }
+            case M_ATTN: {
+                const int C = co;
+                mod.w_gn0_g = pack_copy(pk, P(p), C);
+                mod.w_gn0_b = pack_copy(pk, P(p + 1), C);
+                // NIN W is [in][out] (layers.py:549): transpose to [out][in]; q,k,v stacked -> [3C][C]
+                mod.w_qkv = pk.put((int64_t)3 * C * C);
+                mod.w_qkv_b = pk.put(3 * C);
+                for (int k = 0; k < 3; ++k) {
+                    const float* Wk = P(p + 2 + 2 * k);
+                    const float* bk = P(p + 3 + 2 * k);
+                    for (int o = 0; o < C; ++o) {
+                        for (int i = 0; i < C; ++i)
+                            pk.host[mod.w_qkv + ((int64_t)k * C + o) * C + i] = Wk[(int64_t)i * C + o];
+                        pk.host[mod.w_qkv_b + k * C + o] = bk[o];
+                    }
+                }
+                mod.w_o = pk.put((int64_t)C * C);
+                const float* W3 = P(p + 8);
+                for (int o = 0; o < C; ++o)
+                    for (int i = 0; i < C; ++i) pk.host[mod.w_o + (int64_t)o * C + i] = W3[(int64_t)i * C + o];
+                mod.w_o_b = pack_copy(pk, P(p + 9), C);
+                break;
+            }
+        }
+    }
+    return OK;
+}
+
+// ------------------------------------------------------------------------------------------- plan builder
+struct GnBuf {
+    size_t mean = 0, scale = 0;
+    int64_t beta = -1;
+};
+
+struct Builder {
+    flowse_model* m;
+    Plan* plan;
+    Arena arena;
+    int B;
+
+    Tn alloc(int H, int W, int C) {
+        Tn t;
+        t.B = B; t.H = H; t.W = W; t.C = C;
+        t.off = arena.alloc(t.bytes());
+        return t;
+    }
+    void release(const Tn& t) { if (t.valid()) arena.release(t.off); }
+    void op(const std::string& label, std::function<int(hipStream_t)> f, double flops = 0.0, double bytes = 0.0,
+            bool dominant = false) {
+        plan->ops.push_back(std::move(f));
+        plan->labels.push_back(label);
+        plan->flops.push_back(flops);
+        plan->bytes.push_back(bytes);
+        plan->dominant.push_back(dominant ? 1 : 0);
+    }
+
+    // stats + finalize; returns per-(b,c) mean / scale buffers (caller releases)
+    GnBuf gn(const Tn& a, const Tn* b2, int64_t w_gamma, int64_t w_beta) {
+        flowse_model* M = m;
+        const int C1 = a.C, C2 = b2 ? b2->C : 0, C = C1 + C2, HW = a.H * a.W, Bn = B;
+        const int G = std::min(C / 4, 32);
+        const int nblk = gn_partial_blocks(HW, C);
+        const size_t part = arena.alloc((size_t)Bn * nblk * C * 2 * sizeof(float));
+        GnBuf g;
+        g.mean = arena.alloc((size_t)Bn * C * sizeof(float));
+        g.scale = arena.alloc((size_t)Bn * C * sizeof(float));
+        g.beta = w_beta;
+        const size_t a_off = a.off, b_off = b2 ? b2->off : 0;
+        const bool has2 = b2 != nullptr;
+        op("gn_stats", [=](hipStream_t s) {
+            return launch_gn_stats(M->A(a_off), C1, has2 ? M->A(b_off) : nullptr, C2, Bn, HW, M->A(part), nblk, s);
+        }, 3.0 * Bn * HW * C, 4.0 * Bn * HW * C);
+        const size_t gm = g.mean, gs = g.scale;
+        op("gn_finalize", [=](hipStream_t s) {
+            return launch_gn_finalize(M->A(part), nblk, Bn, HW, C, G, M->W(w_gamma), 1e-6f, M->A(gm), M->A(gs), s);
+        });
+        arena.release(part);
+        return g;
+    }
+    void gn_release(const GnBuf& g) {
+        arena.release(g.mean);
+        arena.release(g.scale);
+    }
+    Tn gn_apply(const Tn& a, const Tn* b2, const GnBuf& g, bool silu) {
+        flowse_model* M = m;
+        const int C1 = a.C, C2 = b2 ? b2->C : 0, HW = a.H * a.W, Bn = B;
+        Tn o = alloc(a.H, a.W, C1 + C2);
+        const size_t a_off = a.off, b_off = b2 ? b2->off : 0, o_off = o.off;
+        const bool has2 = b2 != nullptr;
+        op("gn_apply", [=](hipStream_t s) {
+            GnParams p{M->A(g.mean), M->A(g.scale), M->W(g.beta)};
+            return launch_gn_apply(M->A(a_off), C1, has2 ? M->A(b_off) : nullptr, C2, Bn, HW, p, silu ? 1 : 0,
+                                   M->A(o_off), s);
+        }, 8.0 * Bn * HW * (C1 + C2), 8.0 * Bn * HW * (C1 + C2));
+        return o;
+    }
+    // conv: out (new tensor unless `inplace_res`), res optional
+    Tn conv(const std::string& label, const Tn& a, const Tn* b2, int64_t w, int64_t bias, int dense_row0, int Cout,
+            int taps, const Tn* res, float scale, bool out_is_res = false, bool cin4 = false) {
+        flowse_model* M = m;
+        Tn o = out_is_res ? *res : alloc(a.H, a.W, Cout);
+        const int C1 = a.C, C2 = b2 ? b2->C : 0, H = a.H, Wd = a.W, Bn = B;
+        const size_t a_off = a.off, b_off = b2 ? b2->off : 0, o_off = o.off, r_off = res ? res->off : 0;
+        const bool has2 = b2 != nullptr, hasres = res != nullptr;
+        const size_t table_off = M_table_off;     // by value: the Builder dies before the plan runs
+        const std::string full_label = label + "@" + std::to_string(H) + "x" + std::to_string(Wd) + ":" +
+                                       std::to_string(C1 + C2) + ">" + std::to_string(Cout);
+        op(full_label, [=](hipStream_t s) {
+            ConvArgs c;
+            c.in1 = M->A(a_off);
+            c.in2 = has2 ? M->A(b_off) : nullptr;
+            c.C1 = C1;
+            c.C2 = C2;
+            c.w = M->W(w);
+            c.bias = bias >= 0 ? M->W(bias) : nullptr;
+            c.bias2 = dense_row0 >= 0 ? M->A(table_off) + dense_row0 : nullptr;
+            c.bias2_stride = M->dense_rows;
+            c.res = hasres ? M->A(r_off) : nullptr;
+            c.out = M->A(o_off);
+            c.B = Bn; c.H = H; c.W = Wd; c.Cout = Cout;
+            c.taps = taps;
+            c.scale = scale;
+            return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s);
+        },
+           2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2),
+           4.0 * ((double)Bn * H * Wd * (C1 + C2 + Cout * (hasres ? 2 : 1)) + (double)Cout * taps * (C1 + C2)),
+           !cin4 && Cout > 64);
+        return o;
+    }
+    size_t M_table_off = 0;     // arena offset of the Dense_0 bias table [B][dense_rows]
+
+    Tn fir(const Tn& a, bool up, const GnBuf* g, bool silu, const Tn* add, bool out_is_add = false) {
+        flowse_model* M = m;
+        const int H = a.H, Wd = a.W, C = a.C, Bn = B;
+        Tn o = out_is_add ? *add : (up ? alloc(2 * H, 2 * Wd, C) : alloc(H / 2, Wd / 2, C));
+        const size_t a_off = a.off, o_off = o.off, add_off = add ? add->off : 0;
+        const bool hasg = g != nullptr, hasadd = add != nullptr;
+        GnBuf gb = hasg ? *g : GnBuf();
+        op(up ? "fir_up" : "fir_down", [=](hipStream_t s) {
+            GnParams p{nullptr, nullptr, nullptr};
+            if (hasg) p = GnParams{M->A(gb.mean), M->A(gb.scale), M->W(gb.beta)};
+            if (up)
+                return launch_fir_up(M->A(a_off), Bn, H, Wd, C, p, silu ? 1 : 0, hasadd ? M->A(add_off) : nullptr,
+                                     M->A(o_off), s);
+            return launch_fir_down(M->A(a_off), Bn, H, Wd, C, p, silu ? 1 : 0, M->A(o_off), s);
+        }, (up ? 8.0 * 4 : 32.0 / 4) * Bn * H * Wd * C, 4.0 * Bn * H * Wd * C * (up ? 5.0 : 1.25));
+        return o;
+    }
+
+    // ResnetBlockBigGANpp.forward, layerspp.py:245-274
+    Tn resblock(const Module& mod, const Tn& x1, const Tn* x2) {
+        const float rs2 = 0.70710678118654752440f;
+        GnBuf g0 = gn(x1, x2, mod.w_gn0_g, mod.w_gn0_b);
+        Tn h1, xs;
+        if (!mod.up && !mod.down) {
+            Tn h0 = gn_apply(x1, x2, g0, true);
+            gn_release(g0);
+            h1 = conv("conv0_3x3", h0, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f);
+            release(h0);
+            if (mod.shortcut) xs = conv("conv2_1x1", x1, x2, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f);
+        } else {
+            Tn hr = fir(x1, mod.up, &g0, true, nullptr);
+            Tn xr = fir(x1, mod.up, nullptr, false, nullptr);
+            gn_release(g0);
+            h1 = conv("conv0_3x3", hr, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f);
+            release(hr);
+            xs = conv("conv2_1x1", xr, nullptr, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f);
+            release(xr);
+        }
+        GnBuf g1 = gn(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b);
+        Tn h2 = gn_apply(h1, nullptr, g1, true);
+        gn_release(g1);
+        release(h1);
+        Tn out = conv("conv1_3x3", h2, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, xs.valid() ? &xs : &x1, rs2);
+        release(h2);
+        release(xs);
+        return out;
+    }
+
+    // AttnBlockpp.forward, layerspp.py:75-91
+    Tn attn(const Module& mod, const Tn& x) {
+        flowse_model* M = m;
+        const float rs2 = 0.70710678118654752440f;
+        const int C = x.C, L = x.H * x.W, Bn = B;
+        GnBuf g = gn(x, nullptr, mod.w_gn0_g, mod.w_gn0_b);
+        Tn hn = gn_apply(x, nullptr, g, false);
+        gn_release(g);
+        Tn qkv = conv("attn_qkv", hn, nullptr, mod.w_qkv, mod.w_qkv_b, -1, 3 * C, 1, nullptr, 1.f);
+        release(hn);
+        Tn o = alloc(x.H, x.W, C);
+        const size_t q_off = qkv.off, o_off = o.off;
+        op("attention", [=](hipStream_t s) { return launch_attention(M->A(q_off), Bn, L, C, M->A(o_off), s); },
+           4.0 * Bn * (double)L * L * C, 16.0 * Bn * L * C);
+        release(qkv);
+        Tn out = conv("attn_out", o, nullptr, mod.w_o, mod.w_o_b, -1, C, 1, &x, rs2);
+        release(o);
+        return out;
+    }
+};
+
+// NCSNpp.forward, ncsnpp.py:247-404
+static int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
+    const flowse_config& c = m->cfg;
+    const int L = c.num_levels;
+    if (F != c.image_size) {
+        set_error("F=%d must equal image_size=%d (attention placement, ncsnpp.py:298)", F, c.image_size);
+        return ERR_SHAPE;
+    }
+    if (B < 1 || T < 1 || (T % (1 << (L - 1))) != 0 || (F % (1 << (L - 1))) != 0) {
+        set_error("shape B=%d F=%d T=%d: T and F must be multiples of %d (pad_spec)", B, F, T, 1 << (L - 1));
+        return ERR_SHAPE;
+    }
+    plan->B = B; plan->F = F; plan->T = T;
+    Builder bd;
+    bd.m = m;
+    bd.plan = plan;
+    bd.B = B;
+    flowse_model* M = m;
+    const int nf = c.nf, td = m->temb_dim;
+    size_t mi = 0;
+    auto next = [&]() -> const Module& { return m->mods[mi++]; };
+
+    // ---- time embedding (depends only on t)
+    const Module& gfp = next();
+    const Module& lin1 = next();
+    const Module& lin2 = next();
+    const size_t e0 = bd.arena.alloc((size_t)B * 2 * nf * 4), e1 = bd.arena.alloc((size_t)B * td * 4),
+                 e2 = bd.arena.alloc((size_t)B * td * 4);
+    bd.M_table_off = bd.arena.alloc((size_t)B * m->dense_rows * 4);
+    const size_t table = bd.M_table_off;
+    {
+        const int64_t wg = gfp.w_a, w1 = lin1.w_a, b1 = lin1.w_a_b, w2 = lin2.w_a, b2 = lin2.w_a_b;
+        bd.op("gfp", [=](hipStream_t s) { return launch_gfp(M->call.t, M->W(wg), B, nf, M->A(e0), s); });
+        bd.op("temb_linear1", [=](hipStream_t s) {
+            return launch_linear(M->A(e0), B, 2 * nf, M->W(w1), M->W(b1), td, 1, M->A(e1), td, s);
+        });
+        // act(temb) is the only consumer of temb (layerspp.py:263)
+        bd.op("temb_linear2", [=](hipStream_t s) {
+            return launch_linear(M->A(e1), B, td, M->W(w2), M->W(b2), td, 1, M->A(e2), td, s);
+        });
+        bd.op("dense_table", [=](hipStream_t s) {
+            return launch_linear(M->A(e2), B, td, M->W(M->w_dense), M->W(M->w_dense_b), M->dense_rows, 0,
+                                 M->A(table), M->dense_rows, s);
+        });
+    }
+    // ---- feature pack + input conv
+    Tn in4 = bd.alloc(F, T, 4);
+    {
+        const size_t o = in4.off;
+        bd.op("pack_input", [=](hipStream_t s) { return launch_pack_input(M->call.x, M->call.y, B, F, T, M->A(o), s); });
+    }
+    const Module& cin = next();
+    std::vector<Tn> hs;
+    hs.push_back(bd.conv("conv_in", in4, nullptr, cin.w_a, cin.w_a_b, -1, nf, 9, nullptr, 1.f, false, true));
+    Tn ipyr = in4;
+    // ---- down path
+    for (int lv = 0; lv < L; ++lv) {
+        for (int b = 0; b < c.num_res_blocks; ++b) {
+            Tn h = bd.resblock(next(), hs.back(), nullptr);
+            if (in_list(c.attn_resolutions, c.num_attn, h.H)) {
+                Tn h2 = bd.attn(next(), h);
+                bd.release(h);
+                h = h2;
+            }
+            hs.push_back(h);
+        }
+        if (lv != L - 1) {
+            Tn h = bd.resblock(next(), hs.back(), nullptr);
+            Tn ip2 = bd.fir(ipyr, false, nullptr, false, nullptr);
+            bd.release(ipyr);
+            ipyr = ip2;
+            const Module& cb = next();
+            bd.conv("combine_1x1", ipyr, nullptr, cb.w_a, cb.w_a_b, -1, cb.out_ch, 1, &h, 1.f, true, true);
+            hs.push_back(h);
+        }
+    }
+    bd.release(ipyr);
+    // ---- middle
+    Tn h = bd.resblock(next(), hs.back(), nullptr);
+    {
+        Tn h2 = bd.attn(next(), h);
+        bd.release(h);
+        h = bd.resblock(next(), h2, nullptr);
+        bd.release(h2);
+    }
+    // ---- up path
+    Tn pyr;
+    for (int lv = L - 1; lv >= 0; --lv) {
+        for (int b = 0; b < c.num_res_blocks + 1; ++b) {
+            Tn skip = hs.back();
+            hs.pop_back();
+            Tn h2 = bd.resblock(next(), h, &skip);
+            bd.release(h);
+            bd.release(skip);
+            h = h2;
+        }
+        if (in_list(c.attn_resolutions, c.num_attn, h.H)) {
+            Tn h2 = bd.attn(next(), h);
+            bd.release(h);
+            h = h2;
+        }
+        const Module& gnm = next();
+        const Module& pcv = next();
+        GnBuf g = bd.gn(h, nullptr, gnm.w_a, gnm.w_a_b);
+        Tn ph = bd.gn_apply(h, nullptr, g, true);
+        bd.gn_release(g);
+        if (!pyr.valid()) {
+            pyr = bd.conv("pyramid_conv", ph, nullptr, pcv.w_a, pcv.w_a_b, -1, 4, 9, nullptr, 1.f);
+        } else {
+            Tn up = bd.fir(pyr, true, nullptr, false, nullptr);
+            bd.release(pyr);
+            pyr = bd.conv("pyramid_conv", ph, nullptr, pcv.w_a, pcv.w_a_b, -1, 4, 9, &up, 1.f, true);
+        }
+        bd.release(ph);
+        if (lv != 0) {
+            Tn h2 = bd.resblock(next(), h, nullptr);
+            bd.release(h);
+            h = h2;
+        }
+    }
+    bd.release(h);
+    if (!hs.empty() || mi != m->mods.size()) {
+        set_error("internal: plan consumed %zu of %zu modules, %zu skips left", mi, m->mods.size(), hs.size());
+        return ERR_STATE;
+    }
+    // ---- head (+ solver update)
+    {
+        const size_t p = pyr.off;
+        bd.op("head", [=](hipStream_t s) {
+            return launch_head(M->A(p), M->call.t, M->W(M->w_out), M->W(M->w_out_b), B, F, T, M->call.mode, M->call.x,
+                               M->call.dt, M->call.out, s);
+        });
+    }
+    plan->ws_bytes = bd.arena.peak();
+    return OK;
+}
+
+static int get_plan(flowse_model* m, int B, int F, int T, Plan** out) {
+    if (!m->d_w) {
+        set_error("weights not loaded: call flowse_model_load_weights first");
+        return ERR_STATE;
+    }
+    auto key = std::make_tuple(B, F, T);
+    auto it = m->plans.find(key);
+    if (it == m->plans.end()) {
+        Plan p;
+        const int rc = build_plan(m, &p, B, F, T);
+        if (rc != OK) return rc;
+        it = m->plans.emplace(key, std::move(p)).first;
+    }
+    Plan* p = &it->second;
+    if (p->ws_bytes > m->d_ws_bytes) {
+        // growing the workspace: the stream may still be using the old one
+        FLOWSE_HIP(hipDeviceSynchronize());
+        if (m->d_ws) FLOWSE_HIP(hipFree(m->d_ws));
+        m->d_ws = nullptr;
+        m->d_ws_bytes = 0;
+        FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_ws), p->ws_bytes));
+        m->d_ws_bytes = p->ws_bytes;
+    }
+    *out = p;
+    return OK;
+}
+
+static int prof_event(flowse_model* m, hipEvent_t* e) {
+    if (m->prof_used == m->prof_pool.size()) {
+        hipEvent_t ev;
+        FLOWSE_HIP(hipEventCreate(&ev));
+        m->prof_pool.push_back(ev);
+    }
+    *e = m->prof_pool[m->prof_used++];
+    return OK;
+}
+
+static int run_plan(flowse_model* m, Plan* p, hipStream_t s) {
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const bool prof = m->prof_mode == 1 || (m->prof_mode == 0 && p->dominant[i]);
+        flowse_model::Pending pd;
+        if (prof) {
+            const std::string& name = (m->prof_mode == 0) ? std::string("conv_mfma_128x128") : p->labels[i];
+            auto it = m->prof_label_ix.find(name);
+            if (it == m->prof_label_ix.end()) {
+                it = m->prof_label_ix.emplace(name, (int)m->prof_labels.size()).first;
+                m->prof_labels.push_back(name);
+            }
+            pd.label = it->second;
+            pd.flops = p->flops[i];
+            pd.bytes = p->bytes[i];
+            int rc = prof_event(m, &pd.a);
+            if (rc != OK) return rc;
+            rc = prof_event(m, &pd.b);
+            if (rc != OK) return rc;
+            FLOWSE_HIP(hipEventRecord(pd.a, s));
+        }
+        const int rc = p->ops[i](s);
+        if (rc != OK) return rc;
+        if (prof) {
+            FLOWSE_HIP(hipEventRecord(pd.b, s));
+            m->prof_pending.push_back(pd);
+        }
+    }
+    return OK;
+}
+
+}  // namespace flowse
+
+// =============================================================================================== C ABI
+extern "C" {
+
+int flowse_abi_version(void) { return FLOWSE_ABI_VERSION; }
+const char* flowse_last_error(void) { return g_err; }
+
+int flowse_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int flowse_model_create(const flowse_config* cfg, flowse_model** out) {
+    if (!cfg || !out) {
+        set_error("flowse_model_create: null argument");
+        return ERR_ARG;
+    }
+    flowse_model* m = new flowse_model();
+    m->cfg = *cfg;
+    const int rc = build_structure(m);
+    if (rc != OK) {
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return OK;
+}
+
+void flowse_model_destroy(flowse_model* m) {
+    if (!m) return;
+    if (m->d_w) (void)hipFree(m->d_w);
+    if (m->d_ws) (void)hipFree(m->d_ws);
+    if (m->d_ts) (void)hipFree(m->d_ts);
+    delete m;
+}
+
+int flowse_model_num_params(const flowse_model* m) { return m ? (int)m->params.size() : 0; }
+int flowse_model_num_modules(const flowse_model* m) { return m ? (int)m->mods.size() : 0; }
+int64_t flowse_model_blob_numel(const flowse_model* m) { return m ? m->blob_numel : 0; }
+
+int flowse_model_param_info(const flowse_model* m, int index, char* name, int name_cap, int64_t shape[4], int* ndim,
+                            int64_t* offset) {
+    if (!m || index < 0 || index >= (int)m->params.size()) {
+        set_error("flowse_model_param_info: bad index %d", index);
+        return ERR_ARG;
+    }
+    const ParamInfo& p = m->params[index];
+    if (name && name_cap > 0) {
+        strncpy(name, p.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (shape)
+        for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+    if (ndim) *ndim = p.ndim;
+    if (offset) *offset = p.offset;
+    return OK;
+}
+
+int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel) {
+    if (!m || !blob) {
+        set_error("flowse_model_load_weights: null argument");
+        return ERR_ARG;
+    }
+    if (numel != m->blob_numel) {
+        set_error("flowse_model_load_weights: blob has %lld floats, model needs %lld", (long long)numel,
+                  (long long)m->blob_numel);
+        return ERR_ARG;
+    }
+    Packer pk;
+    const int rc = pack_weights(m, blob, pk);
+    if (rc != OK) return rc;
+    FLOWSE_HIP(hipDeviceSynchronize());
+    if (m->d_w && m->d_w_numel < (int64_t)pk.host.size()) {
+        FLOWSE_HIP(hipFree(m->d_w));
+        m->d_w = nullptr;
+    }
+    if (!m->d_w) {
+        FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_w), pk.host.size() * sizeof(float)));
+        m->d_w_numel = (int64_t)pk.host.size();
+    }
+    FLOWSE_HIP(hipMemcpy(m->d_w, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    m->plans.clear();        // closures captured weight offsets of the previous packing
+    return OK;
+}
+
+int flowse_model_reserve(flowse_model* m, int B, int F, int T, int64_t* workspace_bytes) {
+    if (!m) {
+        set_error("flowse_model_reserve: null model");
+        return ERR_ARG;
+    }
+    Plan* p = nullptr;
+    const int rc = get_plan(m, B, F, T, &p);
+    if (rc != OK) return rc;
+    if (workspace_bytes) *workspace_bytes = (int64_t)p->ws_bytes;
+    return OK;
+}
+
+int flowse_vf_forward(flowse_model* m, const void* x, const void* y, const float* t, void* out, int B, int F, int T,
+                      int mode, void* stream) {
+    if (!m || !x || !y || !t || !out || (mode != 0 && mode != 1)) {
+        set_error("flowse_vf_forward: bad argument");
+        return ERR_ARG;
+    }
+    Plan* p = nullptr;
+    int rc = get_plan(m, B, F, T, &p);
+    if (rc != OK) return rc;
+    m->call.x = static_cast<const float*>(x);
+    m->call.y = static_cast<const float*>(y);
+    m->call.t = t;
+    m->call.out = static_cast<float*>(out);
+    m->call.mode = mode;
+    m->call.dt = 0.f;
+    return run_plan(m, p, static_cast<hipStream_t>(stream));
+}
+
+int flowse_prior_sample(const void* y, const void* z, float sigma, void* x_out, int64_t numel_complex, void* stream) {
+    if (!y || !z || !x_out || numel_complex < 0) {
+        set_error("flowse_prior_sample: bad argument");
+        return ERR_ARG;
+    }
+    return launch_axpy(static_cast<const float*>(y), static_cast<const float*>(z), sigma, 2 * numel_complex,
+                       static_cast<float*>(x_out), static_cast<hipStream_t>(stream));
+}
+
+int flowse_axpy(const void* x, const void* k, float dt, void* out, int64_t numel_complex, void* stream) {
+    return flowse_prior_sample(x, k, dt, out, numel_complex, stream);
+}
+
+int flowse_euler_sample(flowse_model* m, void* x_inout, const void* y, const float* ts, const float* dts, int N, int B,
+                        int F, int T, void* stream) {
+    if (!m || !x_inout || !y || !ts || !dts || N < 1) {
+        set_error("flowse_euler_sample: bad argument");
+        return ERR_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Plan* p = nullptr;
+    int rc = get_plan(m, B, F, T, &p);
+    if (rc != OK) return rc;
+    const size_t need = (size_t)N * B;
+    if (need > m->d_ts_floats) {
+        FLOWSE_HIP(hipDeviceSynchronize());
+        if (m->d_ts) FLOWSE_HIP(hipFree(m->d_ts));
+        m->d_ts = nullptr;
+        FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_ts), need * sizeof(float)));
+        m->d_ts_floats = need;
+    }
+    std::vector<float> host(need);
+    for (int i = 0; i < N; ++i)
+        for (int b = 0; b < B; ++b) host[(size_t)i * B + b] = ts[i];   // vec_t = ones(B) * t, sampling/__init__.py:55
+    // pageable source: the runtime stages the copy before returning, so `host` may die at scope exit
+    FLOWSE_HIP(hipMemcpyAsync(m->d_ts, host.data(), need * sizeof(float), hipMemcpyHostToDevice, s));
+    for (int i = 0; i < N; ++i) {
+        m->call.x = static_cast<const float*>(x_inout);
+        m->call.y = static_cast<const float*>(y);
+        m->call.t = m->d_ts + (size_t)i * B;
+        m->call.out = static_cast<float*>(x_inout);
+        m->call.mode = 2;
+        m->call.dt = dts[i];
+        rc = run_plan(m, p, s);
+        if (rc != OK) return rc;
+    }
+    return OK;
+}
+
+int flowse_profile_begin(flowse_model* m, int mode) {
+    if (!m || (mode != 0 && mode != 1)) {
+        set_error("flowse_profile_begin: bad argument");
+        return ERR_ARG;
+    }
+    m->prof_mode = mode;
+    m->prof_used = 0;
+    m->prof_pending.clear();
+    m->prof_labels.clear();
+    m->prof_label_ix.clear();
+    return OK;
+}
+
+int flowse_profile_end(flowse_model* m, char* json, int cap) {
+    if (!m || !json || cap < 64) {
+        set_error("flowse_profile_end: bad argument");
+        return ERR_ARG;
+    }
+    m->prof_mode = -1;
+    std::vector<ProfAcc> acc(m->prof_labels.size());
+    for (auto& pd : m->prof_pending) {
+        FLOWSE_HIP(hipEventSynchronize(pd.b));
+        float ms = 0.f;
+        FLOWSE_HIP(hipEventElapsedTime(&ms, pd.a, pd.b));
+        ProfAcc& a = acc[pd.label];
+        a.launches += 1;
+        a.ms += ms;
+        a.flops += pd.flops;
+        a.bytes += pd.bytes;
+    }
+    m->prof_pending.clear();
+    m->prof_used = 0;
+    std::string out = "{";
+    for (size_t i = 0; i < acc.size(); ++i) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s\"%s\": {\"launches\": %lld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 i ? ", " : "", m->prof_labels[i].c_str(), (long long)acc[i].launches, acc[i].ms, acc[i].flops,
+                 acc[i].bytes);
+        out += buf;
+    }
+    out += "}";
+    if ((int)out.size() + 1 > cap) {
+        set_error("flowse_profile_end: report needs %zu bytes", out.size() + 1);
+        return ERR_ARG;
+    }
+    memcpy(json, out.c_str(), out.size() + 1);
+    return OK;
+}
+
+int flowse_upfirdn2d(const float* input, const float* kernel, int planes, int in_h, int in_w, int kh, int kw, int up_x,
+                     int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float* out,
+                     int out_h, int out_w, void* stream) {
+    if (!input || !kernel || !out || pad_x0 < 0 || pad_x1 < 0 || pad_y0 < 0 || pad_y1 < 0) {
+        set_error("flowse_upfirdn2d: bad argument (null pointer or negative pad)");
+        return ERR_ARG;
+    }
+    return launch_upfirdn2d_nchw(input, kernel, planes, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+                                 pad_y0, pad_y1, out, out_h, out_w, static_cast<hipStream_t>(stream));
+}
+
+int flowse_op_conv2d(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
+                     const float* bias2, int bias2_stride, const float* res, float* out, int B, int H, int W, int Cout,
+                     int taps, float scale, void* stream) {
+    if (!in1 || !w || !out) {
+        set_error("flowse_op_conv2d: null argument");
+        return ERR_ARG;
+    }
+    ConvArgs c;
+    c.in1 = in1; c.in2 = in2; c.C1 = C1; c.C2 = in2 ? C2 : 0;
+    c.w = w; c.bias = bias; c.bias2 = bias2; c.bias2_stride = bias2_stride; c.res = res; c.out = out;
+    c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = taps; c.scale = scale;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return (C1 == 4 && !in2) ? launch_conv_cin4(c, s) : launch_conv(c, s);
+}
+
+int64_t flowse_op_group_norm_scratch_floats(int B, int HW, int C) {
+    const int nblk = gn_partial_blocks(HW, C);
+    return (int64_t)B * nblk * C * 2 + 2 * (int64_t)B * C;
+}
+
+int flowse_op_group_norm(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
+                         float eps, int silu, float* out, int B, int H, int W, float* scratch, void* stream) {
+    if (!in1 || !gamma || !beta || !out || !scratch) {
+        set_error("flowse_op_group_norm: null argument");
+        return ERR_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!in2) C2 = 0;
+    const int C = C1 + C2, HW = H * W;
+    const int G = std::min(C / 4, 32);
+    const int nblk = gn_partial_blocks(HW, C);
+    float* part = scratch;
+    float* mean = scratch + (int64_t)B * nblk * C * 2;
+    float* scl = mean + (int64_t)B * C;
+    int rc = launch_gn_stats(in1, C1, in2, C2, B, HW, part, nblk, s);
+    if (rc != OK) return rc;
+    rc = launch_gn_finalize(part, nblk, B, HW, C, G, gamma, eps, mean, scl, s);
+    if (rc != OK) return rc;
+    GnParams p{mean, scl, beta};
+    return launch_gn_apply(in1, C1, in2, C2, B, HW, p, silu, out, s);
+}
+
+int flowse_op_fir_up(const float* in, float* out, int B, int H, int W, int C, void* stream) {
+    GnParams p{nullptr, nullptr, nullptr};
+    return launch_fir_up(in, B, H, W, C, p, 0, nullptr, out, static_cast<hipStream_t>(stream));
+}
+int flowse_op_fir_down(const float* in, float* out, int B, int H, int W, int C, void* stream) {
+    GnParams p{nullptr, nullptr, nullptr};
+    return launch_fir_down(in, B, H, W, C, p, 0, out, static_cast<hipStream_t>(stream));
+}
+int flowse_op_attention(const float* qkv, float* out, int B, int L, int C, void* stream) {
+    return launch_attention(qkv, B, L, C, out, static_cast<hipStream_t>(stream));
+}
+int flowse_op_gfp(const float* t, const float* W, float* out, int B, int E, void* stream) {
+    return launch_gfp(t, W, B, E, out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

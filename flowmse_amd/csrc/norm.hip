@@ -1,0 +1,168 @@
+// GroupNorm (+SiLU) for NHWC fp32 tensors, optionally over the channel concat of two tensors.
+//
+// Replaces (reference): nn.GroupNorm(num_groups=min(C//4,32), C, eps=1e-6) followed by SiLU as used in
+// ResnetBlockBigGANpp (flowmse/backbones/ncsnpp_utils/layerspp.py:219,231,246,265), AttnBlockpp (:67,77) and the
+// progressive-output heads (flowmse/backbones/ncsnpp.py:210,222,347,356), incl. the GroupNorm that spans the
+// concat [h, skip] of ncsnpp.py:337 (a group may straddle the two source tensors, e.g. 384 = 256 + 128).
+//
+// Three kernels:
+//   gn_stats     per-(sample, block, channel) partial sum / sum of squares (fp32, <= ~1k terms per partial);
+//                threads own a channel quad (float4) and stride over pixels -> coalesced 16 B/lane streams,
+//                LDS tree over the pixel lanes.  Deterministic (no atomics).
+//   gn_finalize  per-(sample, group) reduction of the partials in fp64 -> mean, rstd; writes per-(b,c)
+//                mean and scale = rstd * gamma (biased variance, as torch).
+//   gn_apply     y = (x - mean) * scale + beta, optional SiLU; writes the (concatenated) tensor.
+// The conv / FIR kernels can also consume GnParams directly (fused apply).
+#include "common.h"
+
+namespace flowse {
+
+constexpr int GN_THREADS = 256;
+
+int gn_partial_blocks(int HW, int C) {
+    // aim for <= 1024 pixels per block, at least 1 block, at most 256 per sample
+    int nblk = (HW + 1023) / 1024;
+    if (nblk < 1) nblk = 1;
+    if (nblk > 256) nblk = 256;
+    (void)C;
+    return nblk;
+}
+
+// grid (nblk, B).  Q = C/4 channel quads; PR = 256 / Q pixel lanes (Q <= 256).
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __restrict__ in1, int C1,
+                                                              const float* __restrict__ in2, int C2, int HW,
+                                                              float* __restrict__ partial, int nblk) {
+    __shared__ float red[GN_THREADS * 8];
+    const int C = C1 + C2, Q = C >> 2;
+    const int PR = GN_THREADS / Q;
+    const int tid = threadIdx.x;
+    const int pr = tid / Q, cq = tid - pr * Q;
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int per = (HW + nblk - 1) / nblk;
+    const int p0 = blk * per, p1 = min(HW, p0 + per);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pr < PR) {
+        const int c = cq * 4;
+        const float* src;
+        int cs, cc;
+        if (c < C1) { src = in1; cs = C1; cc = c; } else { src = in2; cs = C2; cc = c - C1; }
+        src += (int64_t)b * HW * cs + cc;
+        for (int p = p0 + pr; p < p1; p += PR) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)p * cs);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            ss[0] = fmaf(v.x, v.x, ss[0]); ss[1] = fmaf(v.y, v.y, ss[1]);
+            ss[2] = fmaf(v.z, v.z, ss[2]); ss[3] = fmaf(v.w, v.w, ss[3]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = s[j]; red[tid * 8 + 4 + j] = ss[j]; }
+    __syncthreads();
+    // reduce over pixel lanes: thread (0, cq) sums rows 1..PR-1
+    if (pr == 0) {
+        for (int r = 1; r < PR; ++r) {
+            const float* o = red + (r * Q + cq) * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += o[j]; ss[j] += o[4 + j]; }
+        }
+        float* dst = partial + (((int64_t)b * nblk + blk) * C + cq * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dst[2 * j] = s[j]; dst[2 * j + 1] = ss[j]; }
+    }
+}
+
+// grid (G, B), 64 threads.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nblk, int HW, int C,
+                                                         int G, const float* __restrict__ gamma, float eps,
+                                                         float* __restrict__ mean, float* __restrict__ scale) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int cpg = C / G;
+    const int n = nblk * cpg;
+    double s = 0.0, ss = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const int blk = i / cpg, c = g * cpg + (i - blk * cpg);
+        const float* p = partial + (((int64_t)b * nblk + blk) * C + c) * 2;
+        s += (double)p[0];
+        ss += (double)p[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        ss += __shfl_xor(ss, o);
+    }
+    const double cnt = (double)HW * cpg;
+    const double mu = s / cnt;
+    double var = ss / cnt - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float muf = (float)mu;
+    if (lane < cpg) {
+        const int c = g * cpg + lane;
+        mean[(int64_t)b * C + c] = muf;
+        scale[(int64_t)b * C + c] = rstd * gamma[c];
+    }
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); }
+
+// grid-stride over float4 elements of the output [B][HW][C]
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ in1, int C1,
+                                                       const float* __restrict__ in2, int C2, int HW, int64_t total4,
+                                                       GnParams gn, int silu, float* __restrict__ out) {
+    const int C = C1 + C2, Q = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / Q;
+        const int cq = (int)(i - pix * Q);
+        const int c = cq * 4;
+        const int b = (int)(pix / HW);
+        float4 v;
+        if (c < C1) v = *reinterpret_cast<const float4*>(in1 + pix * C1 + c);
+        else v = *reinterpret_cast<const float4*>(in2 + pix * C2 + (c - C1));
+        const float4 mu = *reinterpret_cast<const float4*>(gn.mean + (int64_t)b * C + c);
+        const float4 sc = *reinterpret_cast<const float4*>(gn.scale + (int64_t)b * C + c);
+        const float4 be = *reinterpret_cast<const float4*>(gn.beta + c);
+        float4 o;
+        o.x = fmaf(v.x - mu.x, sc.x, be.x);
+        o.y = fmaf(v.y - mu.y, sc.y, be.y);
+        o.z = fmaf(v.z - mu.z, sc.z, be.z);
+        o.w = fmaf(v.w - mu.w, sc.w, be.w);
+        if (silu) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
+        *reinterpret_cast<float4*>(out + i * 4) = o;
+    }
+}
+
+int launch_gn_stats(const float* in1, int C1, const float* in2, int C2, int B, int HW, float* partial, int nblk,
+                    hipStream_t s) {
+    const int C = C1 + C2;
+    if ((C1 & 3) || (C2 & 3) || C / 4 > GN_THREADS || C <= 0) {
+        set_error("gn_stats: unsupported channels C1=%d C2=%d", C1, C2);
+        return ERR_SHAPE;
+    }
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(GN_THREADS), 0, s, in1, C1, in2, C2, HW, partial, nblk);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+int launch_gn_finalize(const float* partial, int nblk, int B, int HW, int C, int G, const float* gamma, float eps,
+                       float* mean, float* scale, hipStream_t s) {
+    if (C % G != 0 || C / G > 64) {
+        set_error("gn_finalize: unsupported C=%d G=%d", C, G);
+        return ERR_SHAPE;
+    }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial, nblk, HW, C, G, gamma, eps, mean,
+                       scale);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+int launch_gn_apply(const float* in1, int C1, const float* in2, int C2, int B, int HW, GnParams gn, int silu,
+                    float* out, hipStream_t s) {
+    const int64_t total4 = (int64_t)B * HW * ((C1 + C2) / 4);
+    int64_t blocks = (total4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, s, in1, C1, in2, C2, HW, total4, gn, silu,
+                       out);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+}  // namespace flowse

@@ -1,0 +1,119 @@
+"""VFModel facade: the surface of ``flowmse.model.VFModel`` that ``evaluate.py`` touches, without Lightning.
+
+Reference: flowmse/model.py:19-206.  What evaluate.py uses (evaluate.py:64-132): ``load_from_checkpoint``,
+``eval(no_ema=False)`` (= swap the EMA shadow weights in, model.py:92-103), ``.cuda()``, ``.ode``, ``_stft``,
+``_forward_transform``, ``to_audio`` and the model itself as ``VF_fn(x, t, y)`` (= ``-dnn(cat[x,y], t)``,
+model.py:164-170).  Training (loss, optimizer, Lightning hooks, dataloaders) is out of scope.
+"""
+import warnings
+
+import torch
+import torch.nn as nn
+
+from flowmse_amd.backbones import BackboneRegistry
+from flowmse_amd.data_module import SpecTransform
+from flowmse_amd.odes import ODERegistry
+
+
+class VFModel(nn.Module):
+    def __init__(self, backbone="ncsnpp", ode="flowmatching", lr=1e-4, ema_decay=0.999, t_eps=0.03, T_rev=1.0,
+                 loss_abs_exponent=0.5, num_eval_files=10, loss_type="mse", data_module_cls=None, **kwargs):
+        super().__init__()
+        dnn_cls = BackboneRegistry.get_by_name(backbone)
+        self.dnn = dnn_cls(**kwargs)
+        ode_cls = ODERegistry.get_by_name(ode)
+        self.ode = ode_cls(**kwargs)
+        self.lr = lr
+        self.ema_decay = ema_decay
+        self.t_eps = t_eps
+        self.T_rev = T_rev
+        self.ode.T_rev = T_rev
+        self.loss_type = loss_type
+        self.num_eval_files = num_eval_files
+        self.loss_abs_exponent = loss_abs_exponent
+        self.data_module = SpecTransform(**kwargs) if data_module_cls is None else data_module_cls(**kwargs)
+        # EMA state (torch_ema layout: list of tensors in self.parameters() order)
+        self._ema_shadow = None
+        self._ema_backup = None
+        self._error_loading_ema = False
+
+    # ------------------------------------------------------------------ checkpoint / EMA (model.py:81-106)
+    def load_ema_shadow(self, shadow_params):
+        params = [p for p in self.parameters()]
+        trainable = [p for p in params if p.requires_grad]
+        if len(shadow_params) == len(params):
+            target = params
+        elif len(shadow_params) == len(trainable):          # torch_ema keeps requires_grad params only
+            target = trainable
+        else:
+            raise ValueError(f"EMA shadow has {len(shadow_params)} tensors, model has {len(params)} parameters "
+                             f"({len(trainable)} trainable)")
+        for s, p in zip(shadow_params, target):
+            if tuple(s.shape) != tuple(p.shape):
+                raise ValueError(f"EMA shadow shape {tuple(s.shape)} != parameter shape {tuple(p.shape)}")
+        self._ema_shadow = [s.detach().clone().float() for s in shadow_params]
+        self._ema_target = target
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_file, map_location="cpu", **overrides):
+        """Parse a Lightning checkpoint of the reference without Lightning / torch_ema
+        (layout: SURVEY.md section 5: hyper_parameters, state_dict['dnn.*'], ema['shadow_params'])."""
+        ckpt = torch.load(checkpoint_file, map_location=map_location, weights_only=False)
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        hp.pop("data_module_cls", None)
+        for k in ("base_dir", "batch_size", "num_workers", "kwargs"):
+            overrides.pop(k, None)
+        hp.update(overrides)
+        model = cls(**hp)
+        sd = {k[len("dnn."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("dnn.")}
+        model.dnn.load_state_dict(sd)
+        ema = ckpt.get("ema")
+        if ema is not None and "shadow_params" in ema:
+            model.load_ema_shadow(ema["shadow_params"])
+        else:
+            model._error_loading_ema = True
+            warnings.warn("EMA state_dict not found in checkpoint!")
+        return model
+
+    def train(self, mode=True, no_ema=False):
+        res = super().train(mode)
+        if not self._error_loading_ema and self._ema_shadow is not None:
+            with torch.no_grad():
+                if mode is False and not no_ema:
+                    if self._ema_backup is None:
+                        self._ema_backup = [p.detach().clone() for p in self._ema_target]
+                        for p, s in zip(self._ema_target, self._ema_shadow):
+                            p.copy_(s.to(p.device))
+                elif self._ema_backup is not None:
+                    for p, b in zip(self._ema_target, self._ema_backup):
+                        p.copy_(b)
+                    self._ema_backup = None
+        return res
+
+    def eval(self, no_ema=False):
+        return self.train(False, no_ema=no_ema)
+
+    # ------------------------------------------------------------------ vector field
+    def forward(self, x, t, y):
+        """-dnn(cat([x, y], 1), t) (model.py:164-170); x, y complex64 [B,1,F,T] on 'cuda', t float32 [B]."""
+        return self.dnn.vf_call(x, t, y, 1)
+
+    def euler_sample_(self, x, y, timesteps, stepsizes):
+        """Fused N-step Euler loop, in place on x (used by sampling.get_white_box_solver)."""
+        return self.dnn.euler_sample(x, y, timesteps, stepsizes)
+
+    # ------------------------------------------------------------------ spectrogram helpers (model.py:190-203)
+    def to_audio(self, spec, length=None):
+        return self._istft(self._backward_transform(spec), length)
+
+    def _forward_transform(self, spec):
+        return self.data_module.spec_fwd(spec)
+
+    def _backward_transform(self, spec):
+        return self.data_module.spec_back(spec)
+
+    def _stft(self, sig):
+        return self.data_module.stft(sig)
+
+    def _istft(self, spec, length=None):
+        return self.data_module.istft(spec, length)

@@ -1,0 +1,150 @@
+/*
+ * flowse_hip.h -- C ABI of libflowse_hip.so: the MI355X (gfx950) implementation of the flowmse sampling
+ * hot path (Euler ODE loop x NCSN++ vector field).
+ *
+ * Conventions
+ *   - Every function returns an int status (0 = FLOWSE_OK); flowse_last_error() returns a thread-local,
+ *     human readable message for the last non-zero status.  Nothing throws across the ABI.
+ *   - All tensor arguments are RAW DEVICE POINTERS owned by the caller (e.g. torch.Tensor.data_ptr());
+ *     weights and workspace are owned by the model handle.  Exception: arguments documented "host".
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue work and return;
+ *     they never synchronise the device (flowse_model_load_weights and flowse_model_reserve may allocate).
+ *   - One handle per GPU per process; calls on one handle must be serialised by the caller (the reference is
+ *     single-threaded, single-stream, torch.no_grad()).
+ *   - Boundary tensors follow the reference: complex64 interleaved (re, im), [B, 1, F, T] contiguous
+ *     (flowmse/backbones/ncsnpp.py:402-403), F == image_size, T a multiple of 2^(levels-1) (pad_spec,
+ *     flowmse/util/other.py:83-90); time t is float32 [B] in (0, 1].
+ *   - Per-op entry points (flowse_op_*) use the library's internal activation layout NHWC float32
+ *     [B][H][W][C]; they exist for unit parity tests and for callers that fuse their own graphs.
+ *
+ * The reference has no C ABI for this path except the pybind11 `upfirdn2d` operator
+ * (flowmse/backbones/ncsnpp_utils/op/upfirdn2d.cpp:12-22); flowse_upfirdn2d() is its drop-in.  All other
+ * entry points replace PyTorch module calls; each one cites the reference code it stands for.
+ */
+#ifndef FLOWSE_HIP_H
+#define FLOWSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLOWSE_OK 0
+#define FLOWSE_ERR_ARG 1
+#define FLOWSE_ERR_HIP 2
+#define FLOWSE_ERR_STATE 3
+#define FLOWSE_ERR_SHAPE 4
+
+#define FLOWSE_ABI_VERSION 1
+#define FLOWSE_MAX_LEVELS 8
+#define FLOWSE_MAX_ATTN 4
+
+/* Constructor arguments of flowmse.backbones.ncsnpp.NCSNpp that shape the graph (ncsnpp.py:45-67).
+ * The remaining constructor flags are fixed at the reference defaults (biggan blocks, FIR [1,3,3,1],
+ * skip_rescale, output_skip / input_skip progressive branches, 'sum' combine, fourier embedding). */
+typedef struct flowse_config {
+    int32_t nf;                                /* 128 */
+    int32_t num_levels;                        /* len(ch_mult) = 7 */
+    int32_t ch_mult[FLOWSE_MAX_LEVELS];        /* (1,1,2,2,2,2,2) */
+    int32_t num_res_blocks;                    /* 2 */
+    int32_t num_attn;                          /* len(attn_resolutions) = 1 */
+    int32_t attn_resolutions[FLOWSE_MAX_ATTN]; /* (16,) */
+    int32_t image_size;                        /* 256 = number of frequency bins F */
+} flowse_config;
+
+typedef struct flowse_model flowse_model;      /* opaque */
+
+int flowse_abi_version(void);
+const char* flowse_last_error(void);
+/* Number of visible HIP devices (0 on a CPU-only host; never fails). */
+int flowse_device_count(void);
+
+/* ---- model handle -------------------------------------------------------------------------------
+ * flowse_model_create builds the module list of NCSNpp.__init__ (ncsnpp.py:97-245) and its parameter
+ * table on the host only -- no device is touched, so it also works on a CPU-only machine. */
+int flowse_model_create(const flowse_config* cfg, flowse_model** out);
+void flowse_model_destroy(flowse_model* m);
+
+/* Parameter table in the order of NCSNpp.parameters() / state_dict() (the order torch_ema's shadow_params
+ * use, flowmse/model.py:81-103): output_layer.{weight,bias}, then all_modules.{i}.*.  `name` receives the
+ * reference state_dict key; shape[0..ndim) the reference shape; `offset` the element offset of the tensor in
+ * the canonical weight blob (all tensors contiguous, reference layout, back to back in table order). */
+int flowse_model_num_params(const flowse_model* m);
+int flowse_model_num_modules(const flowse_model* m);
+int64_t flowse_model_blob_numel(const flowse_model* m);
+int flowse_model_param_info(const flowse_model* m, int index, char* name, int name_cap, int64_t shape[4],
+                            int* ndim, int64_t* offset);
+
+/* Upload weights.  `blob` is a HOST pointer to flowse_model_blob_numel() floats in canonical order.  The
+ * library re-packs into its kernel-native layouts (channel-last conv weights, transposed NIN, fused q/k/v,
+ * one stacked Dense_0 matrix) on the current HIP device. */
+int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel);
+
+/* Optional: plan buffers for a shape ahead of time (otherwise done lazily by the first call).
+ * `workspace_bytes` (may be NULL) receives the activation workspace size. */
+int flowse_model_reserve(flowse_model* m, int B, int F, int T, int64_t* workspace_bytes);
+
+/* ---- vector field --------------------------------------------------------------------------------
+ * mode 0: out = dnn(cat[x, y], t)     == NCSNpp.forward          (ncsnpp.py:247-404)
+ * mode 1: out = -dnn(cat[x, y], t)    == VFModel.forward(x,t,y)  (flowmse/model.py:164-170)
+ * x, y, out: complex64 [B,1,F,T] device; t: float32 [B] device. */
+int flowse_vf_forward(flowse_model* m, const void* x, const void* y, const float* t, void* out, int B, int F,
+                      int T, int mode, void* stream);
+
+/* ---- sampler --------------------------------------------------------------------------------------
+ * x <- y + sigma * z                                            (FLOWMATCHING.prior_sampling, odes.py:93-100) */
+int flowse_prior_sample(const void* y, const void* z, float sigma, void* x_out, int64_t numel_complex,
+                        void* stream);
+/* N Euler steps in place on x (ode_solver loop, flowmse/sampling/__init__.py:45-57, with
+ * EulerODEsolver.update_fn, sampling/odesolvers.py:42-47):  for i: x <- x + VF(x, ts[i], y) * (-dts[i]).
+ * ts, dts: HOST float32 arrays of length N (the caller reproduces torch.linspace and the step rule, including
+ * the final step dts[N-1] = ts[N-1]).  No host synchronisation. */
+int flowse_euler_sample(flowse_model* m, void* x_inout, const void* y, const float* ts, const float* dts, int N,
+                        int B, int F, int T, void* stream);
+/* One generic explicit update from a caller-held slope: x <- x + dt * k (complex64 as float pairs). */
+int flowse_axpy(const void* x, const void* k, float dt, void* out, int64_t numel_complex, void* stream);
+
+/* ---- in-library kernel timing (used by bench.py for the live roofline figure) -------------------------
+ * Between _begin and _end every selected launch of this handle is bracketed by HIP events on the launch
+ * stream.  mode 0: only launches of the dominant kernel (conv_mfma_kernel, 128x128 tile), reported under the
+ * key "conv_mfma_128x128"; mode 1: every launch, keyed by op label.  _end synchronises on the recorded events
+ * and writes a JSON object {label: {"launches", "ms", "flops", "bytes"}} (algorithmic flops / bytes of the
+ * bracketed launches) into `json`. */
+int flowse_profile_begin(flowse_model* m, int mode);
+int flowse_profile_end(flowse_model* m, char* json, int cap);
+
+/* ---- upfirdn2d: drop-in for the reference's native operator ------------------------------------------
+ * Reference: upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+ * (op/upfirdn2d.cpp:12-22; kernels op/upfirdn2d_kernel.cu:49-207).  input: float32 [planes, in_h, in_w]
+ * (= NCHW with planes = N*C), kernel: float32 [kh, kw] device, out: [planes, out_h, out_w] with
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kh) / down_y + 1 (same for w).  Pads must be >= 0. */
+int flowse_upfirdn2d(const float* input, const float* kernel, int planes, int in_h, int in_w, int kh, int kw,
+                     int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                     float* out, int out_h, int out_w, void* stream);
+
+/* ---- per-op entry points (NHWC float32 device tensors) ------------------------------------------------
+ * conv: out = (conv_{taps}(cat[in1,in2]; w) + bias + bias2[b] + res) * scale.  w: [Cout][taps][C1+C2] (channel
+ * last), taps 9 (3x3, pad 1) or 1; in2/bias/bias2/res may be NULL.  Stands for ddpm_conv3x3 / ddpm_conv1x1 /
+ * NIN (layers.py:100-124, 546-555) with the ResnetBlockBigGANpp epilogue (layerspp.py:262-274). */
+int flowse_op_conv2d(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
+                     const float* bias2, int bias2_stride, const float* res, float* out, int B, int H, int W,
+                     int Cout, int taps, float scale, void* stream);
+/* GroupNorm(min(C/4,32) groups, eps) [+ SiLU] over cat[in1,in2] (layerspp.py:219,231; ncsnpp.py:337).
+ * `scratch` must hold flowse_op_group_norm_scratch_floats(B,H*W,C1+C2) floats. */
+int64_t flowse_op_group_norm_scratch_floats(int B, int HW, int C);
+int flowse_op_group_norm(const float* in1, int C1, const float* in2, int C2, const float* gamma,
+                         const float* beta, float eps, int silu, float* out, int B, int H, int W, float* scratch,
+                         void* stream);
+/* FIR x2 resampling with [1,3,3,1] (up_or_down_sampling.py:195-257). up: out [B,2H,2W,C]; down: [B,H/2,W/2,C] */
+int flowse_op_fir_up(const float* in, float* out, int B, int H, int W, int C, void* stream);
+int flowse_op_fir_down(const float* in, float* out, int B, int H, int W, int C, void* stream);
+/* softmax(q k^T C^-1/2) v over L tokens; qkv [B][L][3C], out [B][L][C] (layerspp.py:82-86). */
+int flowse_op_attention(const float* qkv, float* out, int B, int L, int C, void* stream);
+/* GaussianFourierProjection(log t) (layerspp.py:39-41, ncsnpp.py:259): out [B][2E] */
+int flowse_op_gfp(const float* t, const float* W, float* out, int B, int E, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWSE_HIP_H */

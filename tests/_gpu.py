@@ -1,0 +1,99 @@
+"""Helpers for the -m gpu tests: ctypes calls into libflowse_hip.so on torch 'cuda' tensors."""
+import ctypes as C
+
+import torch
+
+from flowmse_amd import _lib
+
+L = _lib.lib
+
+
+def nhwc(x):
+    """NCHW cpu/any -> NHWC contiguous cuda float32"""
+    return x.permute(0, 2, 3, 1).contiguous().cuda().float()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def stream():
+    return _lib.current_stream()
+
+
+def conv2d(x1, w, bias=None, x2=None, bias2=None, res=None, scale=1.0, padding=None):
+    """x*: NCHW cpu tensors; w: [Cout, Cin, k, k] (reference layout). Returns NCHW cpu."""
+    Cout, Cin, k, _ = w.shape
+    taps = k * k
+    a1 = nhwc(x1)
+    a2 = nhwc(x2) if x2 is not None else None
+    B, H, W, C1 = a1.shape
+    C2 = a2.shape[3] if a2 is not None else 0
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, taps, Cin).contiguous().cuda()
+    bb = bias.contiguous().cuda() if bias is not None else None
+    b2 = bias2.contiguous().cuda() if bias2 is not None else None
+    rr = nhwc(res) if res is not None else None
+    out = torch.empty(B, H, W, Cout, device="cuda")
+    _lib.check(L.flowse_op_conv2d(_lib.ptr(a1), C1, _lib.ptr(a2), C2, _lib.ptr(wp), _lib.ptr(bb), _lib.ptr(b2),
+                                  b2.shape[1] if b2 is not None else 0, _lib.ptr(rr), _lib.ptr(out), B, H, W, Cout,
+                                  taps, float(scale), stream()))
+    torch.cuda.synchronize()
+    return nchw(out)
+
+
+def group_norm(x1, gamma, beta, x2=None, silu=True, eps=1e-6):
+    a1 = nhwc(x1)
+    a2 = nhwc(x2) if x2 is not None else None
+    B, H, W, C1 = a1.shape
+    C2 = a2.shape[3] if a2 is not None else 0
+    n = L.flowse_op_group_norm_scratch_floats(B, H * W, C1 + C2)
+    scratch = torch.empty(n, device="cuda")
+    out = torch.empty(B, H, W, C1 + C2, device="cuda")
+    g, b = gamma.cuda().contiguous(), beta.cuda().contiguous()
+    _lib.check(L.flowse_op_group_norm(_lib.ptr(a1), C1, _lib.ptr(a2), C2, _lib.ptr(g), _lib.ptr(b), eps, int(silu),
+                                      _lib.ptr(out), B, H, W, _lib.ptr(scratch), stream()))
+    torch.cuda.synchronize()
+    return nchw(out)
+
+
+def fir(x, up):
+    a = nhwc(x)
+    B, H, W, Cc = a.shape
+    out = torch.empty((B, 2 * H, 2 * W, Cc) if up else (B, H // 2, W // 2, Cc), device="cuda")
+    fn = L.flowse_op_fir_up if up else L.flowse_op_fir_down
+    _lib.check(fn(_lib.ptr(a), _lib.ptr(out), B, H, W, Cc, stream()))
+    torch.cuda.synchronize()
+    return nchw(out)
+
+
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+    N, Cc, H, W = x.shape
+    kh, kw = kernel.shape
+    oh = (H * up + pad[0] + pad[1] - kh) // down + 1
+    ow = (W * up + pad[0] + pad[1] - kw) // down + 1
+    a = x.contiguous().cuda().float()
+    k = torch.as_tensor(kernel, dtype=torch.float32).contiguous().cuda()
+    out = torch.empty(N, Cc, oh, ow, device="cuda")
+    _lib.check(L.flowse_upfirdn2d(_lib.ptr(a), _lib.ptr(k), N * Cc, H, W, kh, kw, up, up, down, down, pad[0], pad[1],
+                                  pad[0], pad[1], _lib.ptr(out), oh, ow, stream()))
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def attention(q, k, v):
+    """q,k,v: [B, C, L] cpu -> [B, C, L] cpu"""
+    B, Cc, Lt = q.shape
+    qkv = torch.cat([q.permute(0, 2, 1), k.permute(0, 2, 1), v.permute(0, 2, 1)], dim=2).contiguous().cuda()
+    out = torch.empty(B, Lt, Cc, device="cuda")
+    _lib.check(L.flowse_op_attention(_lib.ptr(qkv), _lib.ptr(out), B, Lt, Cc, stream()))
+    torch.cuda.synchronize()
+    return out.permute(0, 2, 1).contiguous().cpu()
+
+
+def gfp(t, W):
+    B, E = t.numel(), W.numel()
+    td, Wd = t.cuda().contiguous(), W.cuda().contiguous()
+    out = torch.empty(B, 2 * E, device="cuda")
+    _lib.check(L.flowse_op_gfp(_lib.ptr(td), _lib.ptr(Wd), _lib.ptr(out), B, E, stream()))
+    torch.cuda.synchronize()
+    return out.cpu()

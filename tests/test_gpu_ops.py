@@ -1,0 +1,142 @@
+"""GPU: per-kernel parity through the C ABI against the CPU oracle / plain torch fp32 on the same seeded inputs.
+
+Tolerance (fp32 path): 1e-5 rel-L2 per op unless stated (north_star bar for the whole sampler: 1e-3).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _cases as C
+from flowmse_amd.util import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def G():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    import _gpu
+    return _gpu
+
+
+def rnd(seed, shape, std=1.0):
+    return torch.from_numpy(synth.normal(77, seed, shape, std))
+
+
+CONV_CASES = [
+    # B, H, W, C1, C2, Cout, k, bias, bias2, res, scale
+    (2, 16, 16, 32, 0, 32, 3, True, False, False, 1.0),
+    (1, 8, 12, 128, 0, 128, 3, True, True, True, 0.70710678),
+    (2, 6, 10, 256, 128, 256, 3, True, True, False, 1.0),      # concat 384, M not multiple of 128
+    (1, 16, 16, 256, 256, 256, 1, True, False, False, 1.0),    # 1x1 on concat 512
+    (3, 4, 4, 64, 0, 192, 1, True, False, False, 1.0),         # qkv-like, tile spans samples
+    (1, 32, 16, 128, 0, 4, 3, True, False, True, 1.0),         # pyramid head (Cout=4) + in-place style residual
+    (2, 8, 8, 16, 0, 16, 3, False, False, False, 1.0),         # tiny-net widths (K chunk padded)
+    (2, 8, 8, 32, 16, 48, 3, True, False, False, 1.0),         # concat 48 (chunk straddles sources)
+    (2, 16, 8, 4, 0, 64, 3, True, False, False, 1.0),          # input layer (direct kernel)
+    (2, 16, 8, 4, 0, 32, 1, True, False, True, 1.0),           # Combine (direct kernel, residual)
+    (1, 64, 64, 128, 0, 128, 3, True, True, True, 0.70710678),  # several M tiles
+    (1, 2, 2, 512, 0, 256, 3, True, False, False, 1.0),        # deep K, tiny image
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(G, case):
+    B, H, W, C1, C2, Cout, k, has_b, has_b2, has_res, scale = case
+    x1 = rnd(1, (B, C1, H, W))
+    x2 = rnd(2, (B, C2, H, W)) if C2 else None
+    w = rnd(3, (Cout, C1 + C2, k, k), (1.0 / ((C1 + C2) * k * k)) ** 0.5)
+    bias = rnd(4, (Cout,), 0.1) if has_b else None
+    bias2 = rnd(5, (B, Cout + 8), 0.1) if has_b2 else None
+    res = rnd(6, (B, Cout, H, W)) if has_res else None
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    ref = F.conv2d(xin, w, bias, padding=k // 2)
+    if has_b2:
+        ref = ref + bias2[:, :Cout, None, None]
+    if has_res:
+        ref = ref + res
+    ref = ref * scale
+    got = G.conv2d(x1, w, bias, x2, bias2, res, scale)
+    assert C.rel_l2(got, ref) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 16, 8), (1, 128, 32, 32), (2, 16, 8, 8), (1, 512, 4, 4),
+                                   (1, 256, 64, 64)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_group_norm(G, shape, silu):
+    B, Cc, H, W = shape
+    x = rnd(10, shape) * 2.0 + 0.7
+    g = 1.0 + rnd(11, (Cc,), 0.2)
+    b = rnd(12, (Cc,), 0.2)
+    ref = F.group_norm(x, min(Cc // 4, 32), g, b, eps=1e-6)
+    if silu:
+        ref = F.silu(ref)
+    assert C.rel_l2(G.group_norm(x, g, b, silu=silu), ref) < TOL
+
+
+@pytest.mark.parametrize("c1,c2", [(256, 128), (32, 16), (256, 256)])
+def test_group_norm_concat_straddle(G, c1, c2):
+    """GroupNorm over cat[h, skip]; for 256+128 group 21 straddles the two tensors (ncsnpp.py:337)."""
+    x1 = rnd(13, (2, c1, 8, 8)) + 1.0
+    x2 = rnd(14, (2, c2, 8, 8)) * 3.0 - 0.5
+    Cc = c1 + c2
+    g = 1.0 + rnd(15, (Cc,), 0.2)
+    b = rnd(16, (Cc,), 0.2)
+    ref = F.silu(F.group_norm(torch.cat([x1, x2], 1), min(Cc // 4, 32), g, b, eps=1e-6))
+    assert C.rel_l2(G.group_norm(x1, g, b, x2=x2, silu=True), ref) < TOL
+
+
+def test_fir_golden(G):
+    g = C.gold("op_fir")
+    x = torch.from_numpy(synth.normal(5, 1, (2, 8, 16, 32)))
+    assert C.rel_l2(G.fir(x, True), g["up"]) < TOL
+    assert C.rel_l2(G.fir(x, False), g["down"]) < TOL
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 2, 2), (2, 16, 6, 10), (1, 128, 32, 48)])
+def test_fir_oracle(G, shape):
+    from oracle import ncsnpp_oracle as O
+    x = rnd(20, shape)
+    assert C.rel_l2(G.fir(x, True), O.upsample_2d(x)) < TOL
+    assert C.rel_l2(G.fir(x, False), O.downsample_2d(x)) < TOL
+
+
+@pytest.mark.parametrize("up,down,pad,ksz", [(2, 1, (2, 1), 4), (1, 2, (1, 1), 4), (1, 1, (1, 1), 3), (2, 2, (3, 2), 4),
+                                            (1, 1, (0, 0), 1)])
+def test_upfirdn2d_nchw(G, up, down, pad, ksz):
+    """Drop-in for the reference's native upfirdn2d ABI (asymmetric random kernel catches a missing flip)."""
+    from oracle import ncsnpp_oracle as O
+    x = rnd(21, (2, 3, 9, 14))
+    k = rnd(22, (ksz, ksz)).numpy()
+    ref = O.upfirdn2d(x, k, up=up, down=down, pad=pad)
+    got = G.upfirdn2d(x, k, up=up, down=down, pad=pad)
+    assert got.shape == ref.shape
+    assert C.rel_l2(got, ref) < TOL
+
+
+@pytest.mark.parametrize("Cc,Lt", [(32, 64), (64, 256), (256, 16), (256, 48), (128, 100), (256, 256)])
+def test_attention(G, Cc, Lt):
+    q, k, v = rnd(30, (2, Cc, Lt)), rnd(31, (2, Cc, Lt)), rnd(32, (2, Cc, Lt))
+    w = torch.einsum("bci,bcj->bij", q, k) * (int(Cc) ** (-0.5))
+    w = F.softmax(w, dim=-1)
+    ref = torch.einsum("bij,bcj->bci", w, v)
+    assert C.rel_l2(G.attention(q, k, v), ref) < TOL
+
+
+def test_attention_peaked(G):
+    """Large logits: the online-softmax rescale path (running max jumps between key tiles)."""
+    Cc, Lt = 64, 128
+    q, k, v = rnd(33, (1, Cc, Lt)) * 4.0, rnd(34, (1, Cc, Lt)) * 4.0, rnd(35, (1, Cc, Lt))
+    k[:, :, 97] = q[:, :, 5] * 3.0          # one key dominates query 5, in the last key tile
+    w = F.softmax(torch.einsum("bci,bcj->bij", q, k) * (int(Cc) ** (-0.5)), dim=-1)
+    ref = torch.einsum("bij,bcj->bci", w, v)
+    assert C.rel_l2(G.attention(q, k, v), ref) < TOL
+
+
+def test_gfp_golden(G):
+    g = C.gold("op_gfp")
+    W = torch.from_numpy(synth.synth_param("gfp.W", (16,)))
+    got = G.gfp(torch.from_numpy(g["t"]), W)
+    assert float((got - torch.from_numpy(g["out"])).abs().max()) < 2e-6

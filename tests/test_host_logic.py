@@ -1,0 +1,161 @@
+"""CPU: host-side logic, the C-ABI surface and the parameter-table contract (no GPU compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import _cases as Cs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from flowmse_amd import _lib
+    header = open(os.path.join(ROOT, "include", "flowse_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(flowse_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(_lib.lib, name), f"{name} declared in flowse_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.lib.flowse_abi_version() == 1
+    assert _lib.lib.flowse_device_count() >= 0
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_param_table_matches_reference(tag):
+    """Keys, shapes and parameters() order of the C-ABI table == the reference NCSNpp's state_dict."""
+    from flowmse_amd.backbones.structure import param_table
+    t = Cs.param_tables()[tag]
+    names, shapes = param_table(t["cfg"])
+    assert names == t["names"] == t["parameters_order"]
+    assert shapes == t["shapes"]
+    assert sum(int(np.prod(s)) for s in shapes) == t["n_params"]
+
+
+def test_facade_state_dict_and_registry():
+    from flowmse_amd.backbones import BackboneRegistry, NCSNpp
+    from flowmse_amd.odes import ODERegistry
+    from flowmse_amd.sampling import ODEsolverRegistry
+    t = Cs.param_tables()["tiny"]
+    assert BackboneRegistry.get_by_name("ncsnpp") is NCSNpp
+    assert "flowmatching" in ODERegistry.get_all_names()
+    assert "euler" in ODEsolverRegistry.get_all_names()
+    with pytest.raises(ValueError):
+        BackboneRegistry.get_by_name("dcunet")
+    m = NCSNpp(**t["cfg"])
+    sd = m.state_dict()
+    assert list(sd.keys()) == t["names"]
+    assert [list(v.shape) for v in sd.values()] == t["shapes"]
+    assert [n for n, _ in m.named_parameters()] == t["parameters_order"]
+    assert not dict(m.named_parameters())["all_modules.0.W"].requires_grad
+    # reference init rules: init_scale=0 tensors ~1e-10 variance, zero biases
+    assert float(sd["all_modules.4.Conv_1.weight"].abs().max()) < 1e-4
+    assert float(sd["all_modules.4.Conv_0.bias"].abs().max()) == 0.0
+    blob = m.canonical_blob()
+    assert blob.numel() == t["n_params"]
+    assert torch.equal(blob[:8], sd["output_layer.weight"].reshape(-1))
+
+
+def test_unsupported_configs_fail_loudly():
+    from flowmse_amd.backbones import NCSNpp
+    from flowmse_amd._lib import FlowseError
+    with pytest.raises(NotImplementedError):
+        NCSNpp(resblock_type="ddpm")
+    with pytest.raises(NotImplementedError):
+        NCSNpp(progressive="none")
+    with pytest.raises(FlowseError):
+        NCSNpp(nf=6)
+    m = NCSNpp(nf=16, ch_mult=(1, 2), image_size=32)
+    x = torch.zeros(1, 2, 32, 32, dtype=torch.complex64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x, torch.ones(1))
+
+
+def test_time_grid_matches_reference_rule():
+    from flowmse_amd.sampling import time_grid
+    g = Cs.gold("tiny_sampler")
+    ts, steps = time_grid(1.0, 0.03, 5)
+    assert np.array_equal(ts.numpy(), g["timesteps_N5"])
+    assert np.array_equal(steps[:-1].numpy(), (ts[:-1] - ts[1:]).numpy())
+    assert float(steps[-1]) == float(ts[-1])            # last step integrates to t = 0
+    ts1, st1 = time_grid(1.0, 0.03, 1)
+    assert float(ts1[0]) == 1.0 and float(st1[0]) == 1.0
+
+
+def test_pad_spec():
+    from flowmse_amd.util.other import pad_spec
+    g = Cs.gold("op_pad_spec")
+    Y = torch.zeros(1, 1, 256, 501, dtype=torch.complex64)
+    assert list(pad_spec(Y).shape) == list(g["shape"])
+    assert pad_spec(torch.zeros(1, 1, 256, 512)).shape[-1] == 512
+    assert pad_spec(torch.zeros(1, 1, 256, 1)).shape[-1] == 64
+
+
+def test_prior_sampling_cpu_semantics():
+    from flowmse_amd.odes import FLOWMATCHING
+    ode = FLOWMATCHING()
+    y = torch.randn(2, 1, 4, 4, dtype=torch.complex64)
+    z = torch.randn(2, 1, 4, 4, dtype=torch.complex64)
+    x, z2 = ode.prior_sampling(y.shape, y, z)
+    assert torch.allclose(x, y + z * 0.487) and z2 is z
+    assert abs(ode.prior_std() - 0.487) < 1e-7
+    assert float(ode._std(torch.tensor([0.5]))) == pytest.approx(0.2435)
+
+
+def test_generic_white_box_solver_on_cpu_callable():
+    """The plugin loop accepts any callable VF_fn (reference semantics), e.g. a closed-form field."""
+    from flowmse_amd.odes import FLOWMATCHING
+    from flowmse_amd.sampling import get_white_box_solver
+    ode = FLOWMATCHING()
+    Y = torch.ones(1, 1, 2, 2, dtype=torch.complex64)
+    z = torch.zeros_like(Y)
+    vf = lambda x, t, y: torch.ones_like(x)            # dx/dt = 1 -> x(0) = x(1) - 1
+    x, n = get_white_box_solver("euler", ode, vf, Y=Y, N=7, z=z)()
+    assert n == 7 and torch.allclose(x, torch.zeros_like(x), atol=1e-6)
+    x, _ = get_white_box_solver("rk4", ode, vf, Y=Y, N=3, z=z)()
+    assert torch.allclose(x, torch.zeros_like(x), atol=1e-6)
+
+
+def test_ema_swap_semantics():
+    """eval(no_ema=False) swaps the EMA shadow weights in, train() restores (model.py:92-103)."""
+    from flowmse_amd.model import VFModel
+    m = VFModel(nf=16, ch_mult=(1, 2), image_size=32)
+    params = list(m.parameters())
+    shadow = [torch.full_like(p, 0.25) for p in params if p.requires_grad]
+    m.load_ema_shadow(shadow)
+    w0 = params[0].detach().clone()
+    m.eval()
+    assert float(params[0].flatten()[0]) == 0.25
+    m.train(True)
+    assert torch.equal(params[0].detach(), w0)
+    m.eval(no_ema=True)
+    assert torch.equal(params[0].detach(), w0)
+    with pytest.raises(ValueError):
+        m.load_ema_shadow(shadow[:-1])
+
+
+def test_shard_utterances_balance():
+    from flowmse_amd.parallel import batches_by_length, shard_utterances
+    lengths = [64 * k for k in [2, 10, 3, 3, 7, 5, 5, 8, 2, 9, 4, 6]]
+    shards = shard_utterances(lengths, 4)
+    assert sorted(i for s in shards for i in s) == list(range(len(lengths)))
+    loads = [sum(lengths[i] for i in s) for s in shards]
+    assert max(loads) - min(loads) <= max(lengths)
+    assert shard_utterances([], 3) == [[], [], []]
+    b = batches_by_length(shards[0], lengths, 2)
+    assert all(len(ids) <= 2 and all(lengths[i] == T for i in ids) for T, ids in b)
+
+
+def test_spec_transform_roundtrip():
+    from flowmse_amd.data_module import SpecTransform
+    st = SpecTransform()
+    sig = torch.randn(1, 16000)
+    S = st.stft(sig)
+    assert S.shape[1] == 256
+    back = st.spec_back(st.spec_fwd(S))
+    assert torch.allclose(back, S, atol=1e-4, rtol=1e-3)
+    assert torch.allclose(st.istft(S, 16000), sig, atol=1e-4)
