@@ -35,31 +35,50 @@ def synth_state_dict(model):
     return {n: torch.from_numpy(synth.synth_param(n, tuple(p.shape))) for n, p in model.named_parameters()}
 
 
-def cpu_baseline(sd, nsolver, frames, reps):
+def cpu_baseline(sd, nsolver, frames, reps, budget_s=60.0):
     """Oracle (CPU restatement of the reference path, 'port') on the host cores: a bounded sample of the same
-    workload -- ONE utterance [1,1,256,frames], ONE Euler step (1 NFE), all host threads -- scaled to N steps."""
+    workload -- ONE utterance [1,1,256,frames], ONE Euler step (1 NFE) -- scaled to N steps.  The torch thread
+    count is chosen by a short sweep at 64 frames (more threads than physical cores can be much slower)."""
     from flowmse_amd.util import synth
     from oracle import ncsnpp_oracle as O
     from oracle import sampler_oracle as S
-    cores = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        logical = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    torch.set_num_threads(cores)
-    y = torch.from_numpy(synth.synth_spectrogram(0, 1, 256, frames))
-    z = torch.from_numpy(synth.synth_noise(0, 1, 256, frames))
     cfg = O.make_cfg()
-    times = []
-    for i in range(reps + 1):
-        t0 = time.perf_counter()
-        S.euler_sample_net(sd, cfg, y, z, N=1)
-        times.append(time.perf_counter() - t0)
-    t_nfe = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": frames / (nsolver * t_nfe), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch-CPU fp32 restatement) 1 utterance [1,1,256,{frames}], 1 Euler step = 1 NFE, "
-                      f"median of {reps} after 1 warm-up = {t_nfe:.3f} s/NFE, scaled to N={nsolver} "
-                      f"(the path is linear in batch and steps); torch threads = {cores}"}
+    t_start = time.perf_counter()
+
+    def nfe_time(T, n):
+        y = torch.from_numpy(synth.synth_spectrogram(0, 1, 256, T))
+        z = torch.from_numpy(synth.synth_noise(0, 1, 256, T))
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            S.euler_sample_net(sd, cfg, y, z, N=1)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    sweep = {}
+    best_n, best_t = None, None
+    for n in [c for c in (8, 16, 32, 64, 96, 128, 192, 256) if c <= logical] or [logical]:
+        torch.set_num_threads(n)
+        t = min(nfe_time(64, 2))
+        sweep[n] = round(t, 3)
+        if best_t is None or t < best_t:
+            best_n, best_t = n, t
+        elif t > 2.0 * best_t or time.perf_counter() - t_start > budget_s / 2:
+            break
+    torch.set_num_threads(best_n)
+    times = nfe_time(frames, reps + 1)[1:]
+    t_nfe = sorted(times)[len(times) // 2]
+    return {"value": frames / (nsolver * t_nfe), "unit": "frames/s", "cores": best_n, "kind": "port",
+            "host_logical_cpus": logical, "thread_sweep_s_per_nfe_at_64_frames": sweep,
+            "sample": f"oracle (torch-CPU fp32 restatement of the reference path) on 1 utterance [1,1,256,{frames}], "
+                      f"1 Euler step = 1 NFE, median of {reps} after 1 warm-up = {t_nfe:.3f} s/NFE with "
+                      f"{best_n} torch threads (best of the sweep), scaled to N={nsolver} steps "
+                      f"(the path is linear in batch and steps)"}
 
 
 def main():
@@ -71,7 +90,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--nsolver", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--profile-all", action="store_true", help="per-op timing table to stderr (extra untimed pass)")
     args = ap.parse_args()
 

@@ -61,8 +61,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs a) 
     }
 
     float4 ra[A_LOADS], rb[B_LOADS];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned okmask = 0;        // bit q: ra[q] valid, bit 16+q: rb[q] valid (applied when staging into LDS)
 
+    // Loads are UNCONDITIONAL on a clamped (always valid) address; the zero-masking happens in lstore(), i.e.
+    // AFTER the MFMA block, so the loads stay in flight under the matrix work.  (A load under a runtime branch,
+    // or a select right behind it, makes hipcc wait vmcnt(0) per element / ahead of the MFMAs.)
     auto gload = [&](int s) {
         const int chunk = s / taps, tap = s - chunk * taps;
         int dy = 0, dx = 0;
@@ -72,40 +75,47 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs a) 
         }
         const int c = chunk * KC + col4 * 4;
         const bool cvalid = c < Cin;
-        const float* src = a.in1;
-        int cs = a.C1, cc = c;
-        if (c >= a.C1) {
-            src = a.in2;
-            cs = a.C2;
-            cc = c - a.C1;
-        }
+        const bool second = cvalid && c >= a.C1;
+        const float* src = second ? a.in2 : a.in1;
+        const int cs = second ? a.C2 : a.C1;
+        const int cc = cvalid ? (second ? c - a.C1 : c) : 0;
         const int shift = dy * W + dx;
+        okmask = 0;
 #pragma unroll
         for (int q = 0; q < A_LOADS; ++q) {
             const int yy = py[q] + dy, xx = px[q] + dx;
             const bool ok = cvalid && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            ra[q] = zero4;
-            if (ok) ra[q] = *reinterpret_cast<const float4*>(src + (int64_t)(pm[q] + shift) * cs + cc);
+            const int64_t off = ok ? (int64_t)(pm[q] + shift) * cs + cc : 0;
+            ra[q] = *reinterpret_cast<const float4*>(src + off);
+            okmask |= ok ? (1u << q) : 0u;
         }
 #pragma unroll
         for (int q = 0; q < B_LOADS; ++q) {
             const int r = row0 + 32 * q;
             const int n = n0 + r;
-            rb[q] = zero4;
-            if (r < BN && cvalid && n < a.Cout)
-                rb[q] = *reinterpret_cast<const float4*>(a.w + ((int64_t)n * taps + tap) * Cin + c);
+            const bool ok = r < BN && cvalid && n < a.Cout;
+            const int64_t off = ok ? ((int64_t)n * taps + tap) * Cin + c : 0;
+            rb[q] = *reinterpret_cast<const float4*>(a.w + off);
+            okmask |= ok ? (1u << (16 + q)) : 0u;
         }
     };
     auto lstore = [&](int buf) {
         float* Ab = As + buf * BM * LDS_ROW;
         float* Bb = Bs + buf * BN * LDS_ROW;
 #pragma unroll
-        for (int q = 0; q < A_LOADS; ++q)
-            *reinterpret_cast<float4*>(Ab + (row0 + 32 * q) * LDS_ROW + col4 * 4) = ra[q];
+        for (int q = 0; q < A_LOADS; ++q) {
+            const bool ok = (okmask >> q) & 1u;
+            float4 v = ra[q];
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            *reinterpret_cast<float4*>(Ab + (row0 + 32 * q) * LDS_ROW + col4 * 4) = v;
+        }
 #pragma unroll
         for (int q = 0; q < B_LOADS; ++q) {
             const int r = row0 + 32 * q;
-            if (r < BN) *reinterpret_cast<float4*>(Bb + r * LDS_ROW + col4 * 4) = rb[q];
+            const bool ok = (okmask >> (16 + q)) & 1u;
+            float4 v = rb[q];
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            if (r < BN) *reinterpret_cast<float4*>(Bb + r * LDS_ROW + col4 * 4) = v;
         }
     };
 
@@ -152,29 +162,52 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs a) 
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[jn].w, acc[i][jn], 0, 0, 0);
                 }
         }
+        __builtin_amdgcn_sched_barrier(0);     // keep the staging (and its vmcnt wait) behind the MFMA block
         if (s + 1 < S) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // ---- epilogue.  The accumulators go through LDS (C/D layout of the 32x32 MFMA: col = lane & 31,
+    // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) so that bias / per-sample bias / residual are read and the
+    // result is written as coalesced float4 rows of the NHWC output.
+    constexpr int CROW = BN + 4;
+    static_assert(BM * CROW <= 2 * (BM + BN) * LDS_ROW, "C tile must fit in the staging buffers");
+    float* Cs = smem;                          // [BM][CROW]; safe: the last loop iteration ended with a barrier
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-            const int n = n0 + (wn * TN + jn) * 32 + li;
-            if (n >= a.Cout) continue;
-            const float bn = a.bias ? a.bias[n] : 0.f;
+        for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int m = m0 + (wm * TM + i) * 32 + row;
-                if (m >= M) continue;
-                float v = acc[i][jn][r] + bn;
-                if (a.bias2) v += a.bias2[(int64_t)(m / HW) * a.bias2_stride + n];
-                const int64_t o = (int64_t)m * a.Cout + n;
-                if (a.res) v += a.res[o];
-                a.out[o] = v * a.scale;
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                Cs[row * CROW + (wn * TN + jn) * 32 + li] = acc[i][jn][r];
             }
+    __syncthreads();
+    constexpr int C4 = BN / 4;                 // float4 per tile row
+    constexpr int RPP = NT / C4;               // rows per pass
+    const int ec4 = tid % C4, er0 = tid / C4;
+    const int n = n0 + ec4 * 4;
+    if (n < a.Cout) {                          // Cout % 4 == 0: a quad is entirely inside or outside
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + n);
+        const bool has_b2 = a.bias2 != nullptr, has_res = a.res != nullptr;
+#pragma unroll 4
+        for (int rr = er0; rr < BM; rr += RPP) {
+            const int m = m0 + rr;
+            if (m >= M) break;
+            float4 v = *reinterpret_cast<const float4*>(Cs + rr * CROW + ec4 * 4);
+            v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+            if (has_b2) {
+                const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)(m / HW) * a.bias2_stride + n);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            const int64_t o = (int64_t)m * a.Cout + n;
+            if (has_res) {
+                const float4 t = *reinterpret_cast<const float4*>(a.res + o);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
+            *reinterpret_cast<float4*>(a.out + o) = v;
         }
     }
 }
@@ -197,7 +230,8 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
-    if ((a.C1 & 3) || (a.C2 & 3) || (a.taps != 1 && a.taps != 9) || a.C1 <= 0 || (a.in2 == nullptr && a.C2 != 0)) {
+    if ((a.C1 & 3) || (a.C2 & 3) || (a.Cout & 3) || (a.bias2 && (a.bias2_stride & 3)) || (a.taps != 1 && a.taps != 9) ||
+        a.C1 <= 0 || (a.in2 == nullptr && a.C2 != 0)) {
         set_error("conv: unsupported channel counts C1=%d C2=%d taps=%d", a.C1, a.C2, a.taps);
         return ERR_SHAPE;
     }

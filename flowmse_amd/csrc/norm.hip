@@ -20,10 +20,10 @@ namespace flowse {
 constexpr int GN_THREADS = 256;
 
 int gn_partial_blocks(int HW, int C) {
-    // aim for <= 1024 pixels per block, at least 1 block, at most 256 per sample
-    int nblk = (HW + 1023) / 1024;
+    // <= 256 pixels per block (enough blocks in flight to stream at HBM rate), at most 512 per sample
+    int nblk = (HW + 255) / 256;
     if (nblk < 1) nblk = 1;
-    if (nblk > 256) nblk = 256;
+    if (nblk > 512) nblk = 512;
     (void)C;
     return nblk;
 }
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __res
         int cs, cc;
         if (c < C1) { src = in1; cs = C1; cc = c; } else { src = in2; cs = C2; cc = c - C1; }
         src += (int64_t)b * HW * cs + cc;
+#pragma unroll 4
         for (int p = p0 + pr; p < p1; p += PR) {
             const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)p * cs);
             s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
