@@ -50,8 +50,14 @@ struct ConvArgs {
     int B, H, W, Cout;
     int taps;           // 9 (3x3, pad 1) or 1 (1x1)
     float scale;        // out = (acc + bias + bias2 + res) * scale
+    // split-K (small images): K steps are divided over gridDim.y slices, each slice writes its raw partial
+    // tile to `partial` [ksplit][B*H*W][Cout]; splitk_reduce sums the slices and applies the epilogue.
+    int ksplit = 1;
+    float* partial = nullptr;
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
+// number of K slices launch_conv will use for this shape (1 = no split) and the partial-buffer size in floats
+int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps);
 
 // direct conv for 4 input channels (input layer, Combine): VALU, HBM-bound
 int launch_conv_cin4(const ConvArgs& a, hipStream_t s);

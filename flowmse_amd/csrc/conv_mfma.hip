@@ -16,6 +16,8 @@
 // packed weights; both are register-staged into double-buffered LDS with a row stride of 36 floats, which
 // makes the fragment ds_read_b128 conflict-free.  Each lane reads 4 consecutive k of its row once and feeds
 // 4 successive MFMAs with them (lanes 0-31 carry k = 8j+e, lanes 32-63 carry k = 8j+4+e, for A and B alike).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace flowse {
@@ -24,6 +26,71 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC = 32;          // channels per K step
 constexpr int LDS_ROW = 36;     // floats per LDS tile row (KC + 4 pad)
+
+// ---- shared epilogue.  The accumulators go through LDS (C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) so that bias / per-sample bias / residual are read and the result
+// is written as coalesced float4 rows of the NHWC output.  Precondition: all waves are past their last LDS read.
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
+                                              int M, int HW, int split) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, kh = lane >> 5;
+    constexpr int CROW = BN + 4;
+    static_assert(BM * CROW <= 2 * (BM + BN) * LDS_ROW, "C tile must fit in the staging buffers");
+    float* Cs = smem;                          // [BM][CROW]; safe: the last loop iteration ended with a barrier
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                Cs[row * CROW + (wn * TN + jn) * 32 + li] = acc[i][jn][r];
+            }
+    __syncthreads();
+    constexpr int C4 = BN / 4;                 // float4 per tile row
+    constexpr int RPP = NT / C4;               // rows per pass
+    const int ec4 = tid % C4, er0 = tid / C4;
+    const int n = n0 + ec4 * 4;
+    if (a.partial) {                           // split-K slice: raw partial sums, epilogue in splitk_reduce
+        if (n < a.Cout) {
+            float* dst = a.partial + (int64_t)split * M * a.Cout;
+            for (int rr = er0; rr < BM; rr += RPP) {
+                const int m = m0 + rr;
+                if (m >= M) break;
+                *reinterpret_cast<float4*>(dst + (int64_t)m * a.Cout + n) =
+                    *reinterpret_cast<const float4*>(Cs + rr * CROW + ec4 * 4);
+            }
+        }
+        return;
+    }
+    if (n < a.Cout) {                          // Cout % 4 == 0: a quad is entirely inside or outside
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + n);
+        const bool has_b2 = a.bias2 != nullptr, has_res = a.res != nullptr;
+#pragma unroll 4
+        for (int rr = er0; rr < BM; rr += RPP) {
+            const int m = m0 + rr;
+            if (m >= M) break;
+            float4 v = *reinterpret_cast<const float4*>(Cs + rr * CROW + ec4 * 4);
+            v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+            if (has_b2) {
+                const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)(m / HW) * a.bias2_stride + n);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            const int64_t o = (int64_t)m * a.Cout + n;
+            if (has_res) {
+                const float4 t = *reinterpret_cast<const float4*>(a.res + o);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
+            *reinterpret_cast<float4*>(a.out + o) = v;
+        }
+    }
+}
 
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs a) {
@@ -41,6 +108,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs a) 
     const int taps = a.taps;
     const int n_ntiles = (a.Cout + BN - 1) / BN;
     const int mt = blockIdx.x / n_ntiles, nt = blockIdx.x - mt * n_ntiles;
+    const int split = blockIdx.y;
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- per-thread gather bookkeeping: this thread always loads channel quad `col4` of rows row0 + 32q
@@ -132,14 +200,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs a) 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nchunks = (Cin + KC - 1) / KC;
-    const int S = nchunks * taps;
+    const int S_all = nchunks * taps;
+    const int per = (S_all + a.ksplit - 1) / a.ksplit;
+    const int s_begin = split * per;
+    const int S = min(S_all, s_begin + per);       // this slice walks steps [s_begin, S)
 
-    gload(0);
+    gload(s_begin);
     lstore(0);
     __syncthreads();
 
-    for (int s = 0; s < S; ++s) {
-        const int buf = s & 1;
+    for (int s = s_begin; s < S; ++s) {
+        const int buf = (s - s_begin) & 1;
         if (s + 1 < S) gload(s + 1);          // global loads stay in flight under the MFMAs
         const float* Ab = As + buf * BM * LDS_ROW + (wm * TM * 32 + li) * LDS_ROW + kh * 4;
         const float* Bb = Bs + buf * BN * LDS_ROW + (wn * TN * 32 + li) * LDS_ROW + kh * 4;
@@ -167,50 +238,165 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs a) 
         __syncthreads();
     }
 
-    // ---- epilogue.  The accumulators go through LDS (C/D layout of the 32x32 MFMA: col = lane & 31,
-    // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) so that bias / per-sample bias / residual are read and the
-    // result is written as coalesced float4 rows of the NHWC output.
-    constexpr int CROW = BN + 4;
-    static_assert(BM * CROW <= 2 * (BM + BN) * LDS_ROW, "C tile must fit in the staging buffers");
-    float* Cs = smem;                          // [BM][CROW]; safe: the last loop iteration ended with a barrier
+    conv_epilogue<WM, WN, TM, TN>(a, acc, smem, m0, n0, M, HW, split);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fast path for the production shapes: C1 % 32 == 0 and C2 % 32 == 0, so every K step (tap, 32-channel chunk)
+// lies in ONE source tensor and is full.  Everything that varies per step is wave-uniform and lives in SGPRs
+// (buffer descriptor + soffset); per lane only a 9-bit tap-validity mask and one byte offset per gathered row
+// are kept.  Out-of-image taps (conv zero padding), rows past M and channels past Cout are redirected to an
+// out-of-range buffer offset, for which the hardware returns 0 -- no masking VALU, no branches, ~10 VALU per
+// step next to 64 MFMAs.  The block addresses its inputs through a window descriptor based at pixel
+// m0 - W - 1, so offsets stay small whatever the tensor size.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArgs a) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
+    constexpr int A_LOADS = BM * 8 / NT, B_LOADS = BN * 8 / NT;
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tiles must split evenly");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDS_ROW;
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int M = a.B * HW;
+    const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
+    const int taps = a.taps;
+    const int n_ntiles = (a.Cout + BN - 1) / BN;
+    const int mt = blockIdx.x / n_ntiles, nt = blockIdx.x - mt * n_ntiles;
+    const int split = blockIdx.y;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int col4 = tid & 7, row0 = tid >> 3;
+    // per gathered row: byte offset inside the window for each source, and which taps fall inside the image
+    unsigned avo1[A_LOADS], avo2[A_LOADS], tapmask[A_LOADS];
+#pragma unroll
+    for (int q = 0; q < A_LOADS; ++q) {
+        const int r = row0 + 32 * q;
+        const int m = m0 + r;
+        avo1[q] = (unsigned)(r * C1 + col4 * 4) * 4u;
+        avo2[q] = (unsigned)(r * C2 + col4 * 4) * 4u;
+        unsigned mask = 0;
+        if (m < M) {
+            const int rem = m % HW;
+            const int y = rem / W, x = rem - y * W;
+            if (taps == 9) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) mask |= 1u << t;
+                }
+            } else {
+                mask = 1u;
+            }
+        }
+        tapmask[q] = mask;
+    }
+    unsigned bvo[B_LOADS];
+#pragma unroll
+    for (int q = 0; q < B_LOADS; ++q) {
+        const int n = n0 + row0 + 32 * q;
+        bvo[q] = n < a.Cout ? (unsigned)(n * taps * Cin + col4 * 4) * 4u : OOB;
+    }
+    // window descriptors (wave-uniform): base = pixel (m0 - W - 1), BM + 2W + 2 pixels long
+    const int64_t wbase = (int64_t)m0 - W - 1;
+    const int wpix = BM + 2 * W + 2;
+    const __amdgpu_buffer_rsrc_t rsrc1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1 + wbase * C1), 0, wpix * C1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(C2 ? a.in2 + wbase * C2 : a.in1), 0, C2 ? wpix * C2 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.Cout * taps * Cin * 4, 0x00020000);
+
+    u32x4 ra[A_LOADS], rb[B_LOADS];
+
+    auto gload = [&](int s) {
+        const int chunk = s / taps, tap = s - chunk * taps;
+        int shift = W + 1;                                    // window origin is pixel m0 - W - 1
+        if (taps == 9) shift += (tap / 3 - 1) * W + (tap - (tap / 3) * 3 - 1);
+        const int c0 = chunk * KC;
+        const bool second = c0 >= C1;
+        const unsigned soff_a = (unsigned)(second ? shift * C2 + (c0 - C1) : shift * C1 + c0) * 4u;
+        const unsigned soff_b = (unsigned)(tap * Cin + c0) * 4u;
+#pragma unroll
+        for (int q = 0; q < A_LOADS; ++q) {
+            const bool ok = (tapmask[q] >> tap) & 1u;
+            const unsigned vo = ok ? (second ? avo2[q] : avo1[q]) : OOB;
+            ra[q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, vo, soff_a, 0)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, vo, soff_a, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < B_LOADS; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo[q], soff_b, 0);
+    };
+    auto lstore = [&](int buf) {
+        float* Ab = As + buf * BM * LDS_ROW;
+        float* Bb = Bs + buf * BN * LDS_ROW;
+#pragma unroll
+        for (int q = 0; q < A_LOADS; ++q)
+            *reinterpret_cast<u32x4*>(Ab + (row0 + 32 * q) * LDS_ROW + col4 * 4) = ra[q];
+#pragma unroll
+        for (int q = 0; q < B_LOADS; ++q)
+            *reinterpret_cast<u32x4*>(Bb + (row0 + 32 * q) * LDS_ROW + col4 * 4) = rb[q];
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, kh = lane >> 5;
+
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                Cs[row * CROW + (wn * TN + jn) * 32 + li] = acc[i][jn][r];
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int S_all = (Cin / KC) * taps;
+    const int per = (S_all + a.ksplit - 1) / a.ksplit;
+    const int s_begin = split * per;
+    const int S = min(S_all, s_begin + per);
+
+    gload(s_begin);
+    lstore(0);
     __syncthreads();
-    constexpr int C4 = BN / 4;                 // float4 per tile row
-    constexpr int RPP = NT / C4;               // rows per pass
-    const int ec4 = tid % C4, er0 = tid / C4;
-    const int n = n0 + ec4 * 4;
-    if (n < a.Cout) {                          // Cout % 4 == 0: a quad is entirely inside or outside
-        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + n);
-        const bool has_b2 = a.bias2 != nullptr, has_res = a.res != nullptr;
-#pragma unroll 4
-        for (int rr = er0; rr < BM; rr += RPP) {
-            const int m = m0 + rr;
-            if (m >= M) break;
-            float4 v = *reinterpret_cast<const float4*>(Cs + rr * CROW + ec4 * 4);
-            v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
-            if (has_b2) {
-                const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)(m / HW) * a.bias2_stride + n);
-                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
-            const int64_t o = (int64_t)m * a.Cout + n;
-            if (has_res) {
-                const float4 t = *reinterpret_cast<const float4*>(a.res + o);
-                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
-            v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
-            *reinterpret_cast<float4*>(a.out + o) = v;
+
+    for (int s = s_begin; s < S; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < S) gload(s + 1);
+        const float* Ab = As + buf * BM * LDS_ROW + (wm * TM * 32 + li) * LDS_ROW + kh * 4;
+        const float* Bb = Bs + buf * BN * LDS_ROW + (wn * TN * 32 + li) * LDS_ROW + kh * 4;
+#pragma unroll
+        for (int j = 0; j < KC / 8; ++j) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + j * 8);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                bf[i] = *reinterpret_cast<const float4*>(Bb + i * 32 * LDS_ROW + j * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[jn].x, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[jn].y, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[jn].z, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[jn].w, acc[i][jn], 0, 0, 0);
+                }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < S) lstore(buf ^ 1);
+        __syncthreads();
     }
+    conv_epilogue<WM, WN, TM, TN>(a, acc, smem, m0, n0, M, HW, split);
 }
+
+// test hook: FLOWSE_FORCE_GENERIC_CONV=1 routes every shape through the generic gather kernel
+static const bool g_force_generic = getenv("FLOWSE_FORCE_GENERIC_CONV") != nullptr;
 
 template <int WM, int WN, int TM, int TN>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
@@ -222,11 +408,68 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     if (!attr_done) {
         FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_fast_kernel<WM, WN, TM, TN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    // fast path: every K step is a full 32-channel chunk of one source; window / weight offsets fit 31 bits
+    const bool fast = (a.C1 % KC) == 0 && (a.C2 % KC) == 0 &&
+                      (int64_t)(BM + 2 * a.W + 2) * (a.C1 > a.C2 ? a.C1 : a.C2) * 4 < (1LL << 31) &&
+                      (int64_t)a.Cout * a.taps * (a.C1 + a.C2) * 4 < (1LL << 31) && !g_force_generic;
+    if (fast)
+        hipLaunchKernelGGL((conv_mfma_fast_kernel<WM, WN, TM, TN>), dim3(grid, a.ksplit), dim3(64 * WM * WN), lds, s, a);
+    else
+        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN>), dim3(grid, a.ksplit), dim3(64 * WM * WN), lds, s, a);
     FLOWSE_LAUNCH_CHECK();
     return OK;
+}
+
+// out = (sum_s partial[s] + bias + bias2 + res) * scale, float4 streams
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, int64_t total4) {
+    const int Q = a.Cout >> 2;
+    const int HW = a.H * a.W;
+    const int64_t slice = (int64_t)a.B * HW * a.Cout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / Q;
+        const int n = (int)(i - m * Q) * 4;
+        float4 v = *reinterpret_cast<const float4*>(a.partial + i * 4);
+        for (int s = 1; s < a.ksplit; ++s) {
+            const float4 t = *reinterpret_cast<const float4*>(a.partial + s * slice + i * 4);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (a.bias) {
+            const float4 t = *reinterpret_cast<const float4*>(a.bias + n);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (a.bias2) {
+            const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (m / HW) * a.bias2_stride + n);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (a.res) {
+            const float4 t = *reinterpret_cast<const float4*>(a.res + i * 4);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
+        *reinterpret_cast<float4*>(a.out + i * 4) = v;
+    }
+}
+
+// Split-K policy: images so small that the 128x128 tiling yields < 256 blocks (one per CU) are sliced along K
+// until ~512 blocks exist, keeping >= 4 K steps per slice.
+int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
+    if (Cout <= 64) return 1;
+    const int64_t M = (int64_t)B * H * W;
+    const int64_t tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
+    const int steps = ((Cin + KC - 1) / KC) * taps;
+    if (tiles >= 256 || steps < 8) return 1;
+    int64_t want = (512 + tiles - 1) / tiles;
+    int64_t maxs = steps / 4;
+    int64_t ks = want < maxs ? want : maxs;
+    if (ks < 1) ks = 1;
+    // make every slice non-empty
+    const int per = (int)((steps + ks - 1) / ks);
+    ks = (steps + per - 1) / per;
+    return (int)ks;
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
@@ -241,6 +484,20 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     }
     if (a.Cout <= 32) return launch_cfg<4, 1, 1, 1>(a, s);
     if (a.Cout <= 64) return launch_cfg<2, 2, 2, 1>(a, s);
+    if (a.ksplit > 1) {
+        if (!a.partial) {
+            set_error("conv: split-K needs a partial buffer");
+            return ERR_ARG;
+        }
+        const int rc = launch_cfg<2, 2, 2, 2>(a, s);
+        if (rc != OK) return rc;
+        const int64_t total4 = (int64_t)a.B * a.H * a.W * (a.Cout / 4);
+        int64_t blocks = (total4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, a, total4);
+        FLOWSE_LAUNCH_CHECK();
+        return OK;
+    }
     return launch_cfg<2, 2, 2, 2>(a, s);
 }
 

@@ -518,6 +518,8 @@ struct Builder {
         const int C1 = a.C, C2 = b2 ? b2->C : 0, H = a.H, Wd = a.W, Bn = B;
         const size_t a_off = a.off, b_off = b2 ? b2->off : 0, o_off = o.off, r_off = res ? res->off : 0;
         const bool has2 = b2 != nullptr, hasres = res != nullptr;
+        const int ks = cin4 ? 1 : conv_ksplit(Bn, H, Wd, C1 + C2, Cout, taps);
+        const size_t part_off = ks > 1 ? arena.alloc((size_t)ks * Bn * H * Wd * Cout * sizeof(float)) : 0;
         const size_t table_off = M_table_off;     // by value: the Builder dies before the plan runs
         const std::string full_label = label + "@" + std::to_string(H) + "x" + std::to_string(Wd) + ":" +
                                        std::to_string(C1 + C2) + ">" + std::to_string(Cout);
@@ -536,11 +538,14 @@ struct Builder {
             c.B = Bn; c.H = H; c.W = Wd; c.Cout = Cout;
             c.taps = taps;
             c.scale = scale;
+            c.ksplit = ks;
+            c.partial = ks > 1 ? M->A(part_off) : nullptr;
             return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s);
         },
            2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2),
            4.0 * ((double)Bn * H * Wd * (C1 + C2 + Cout * (hasres ? 2 : 1)) + (double)Cout * taps * (C1 + C2)),
            !cin4 && Cout > 64);
+        if (ks > 1) arena.release(part_off);
         return o;
     }
     size_t M_table_off = 0;     // arena offset of the Dense_0 bias table [B][dense_rows]
@@ -1047,9 +1052,14 @@ int flowse_upfirdn2d(const float* input, const float* kernel, int planes, int in
                                  pad_y0, pad_y1, out, out_h, out_w, static_cast<hipStream_t>(stream));
 }
 
+int64_t flowse_op_conv2d_scratch_floats(int B, int H, int W, int Cin, int Cout, int taps) {
+    const int ks = conv_ksplit(B, H, W, Cin, Cout, taps);
+    return ks > 1 ? (int64_t)ks * B * H * W * Cout : 0;
+}
+
 int flowse_op_conv2d(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
                      const float* bias2, int bias2_stride, const float* res, float* out, int B, int H, int W, int Cout,
-                     int taps, float scale, void* stream) {
+                     int taps, float scale, float* splitk_scratch, void* stream) {
     if (!in1 || !w || !out) {
         set_error("flowse_op_conv2d: null argument");
         return ERR_ARG;
@@ -1059,7 +1069,12 @@ int flowse_op_conv2d(const float* in1, int C1, const float* in2, int C2, const f
     c.w = w; c.bias = bias; c.bias2 = bias2; c.bias2_stride = bias2_stride; c.res = res; c.out = out;
     c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = taps; c.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return (C1 == 4 && !in2) ? launch_conv_cin4(c, s) : launch_conv(c, s);
+    if (C1 == 4 && !in2) return launch_conv_cin4(c, s);
+    if (splitk_scratch) {
+        c.ksplit = conv_ksplit(B, H, W, c.C1 + c.C2, Cout, taps);
+        c.partial = c.ksplit > 1 ? splitk_scratch : nullptr;
+    }
+    return launch_conv(c, s);
 }
 
 int64_t flowse_op_group_norm_scratch_floats(int B, int HW, int C) {

@@ -129,7 +129,11 @@ int flowse_upfirdn2d(const float* input, const float* kernel, int planes, int in
  * NIN (layers.py:100-124, 546-555) with the ResnetBlockBigGANpp epilogue (layerspp.py:262-274). */
 int flowse_op_conv2d(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
                      const float* bias2, int bias2_stride, const float* res, float* out, int B, int H, int W,
-                     int Cout, int taps, float scale, void* stream);
+                     int Cout, int taps, float scale, float* splitk_scratch, void* stream);
+/* Small images are computed split-K (K sliced over extra thread blocks, deterministic two-pass reduction) when
+ * `splitk_scratch` holds flowse_op_conv2d_scratch_floats(...) floats (0 = this shape never splits); with
+ * splitk_scratch == NULL the single-pass kernel is used. */
+int64_t flowse_op_conv2d_scratch_floats(int B, int H, int W, int Cin, int Cout, int taps);
 /* GroupNorm(min(C/4,32) groups, eps) [+ SiLU] over cat[in1,in2] (layerspp.py:219,231; ncsnpp.py:337).
  * `scratch` must hold flowse_op_group_norm_scratch_floats(B,H*W,C1+C2) floats. */
 int64_t flowse_op_group_norm_scratch_floats(int B, int HW, int C);

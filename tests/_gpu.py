@@ -21,7 +21,7 @@ def stream():
     return _lib.current_stream()
 
 
-def conv2d(x1, w, bias=None, x2=None, bias2=None, res=None, scale=1.0, padding=None):
+def conv2d(x1, w, bias=None, x2=None, bias2=None, res=None, scale=1.0, padding=None, splitk=False):
     """x*: NCHW cpu tensors; w: [Cout, Cin, k, k] (reference layout). Returns NCHW cpu."""
     Cout, Cin, k, _ = w.shape
     taps = k * k
@@ -34,9 +34,14 @@ def conv2d(x1, w, bias=None, x2=None, bias2=None, res=None, scale=1.0, padding=N
     b2 = bias2.contiguous().cuda() if bias2 is not None else None
     rr = nhwc(res) if res is not None else None
     out = torch.empty(B, H, W, Cout, device="cuda")
+    scratch = None
+    if splitk:
+        n = L.flowse_op_conv2d_scratch_floats(B, H, W, C1 + C2, Cout, taps)
+        scratch = torch.empty(max(n, 1), device="cuda")
+        conv2d.last_split = n > 0
     _lib.check(L.flowse_op_conv2d(_lib.ptr(a1), C1, _lib.ptr(a2), C2, _lib.ptr(wp), _lib.ptr(bb), _lib.ptr(b2),
                                   b2.shape[1] if b2 is not None else 0, _lib.ptr(rr), _lib.ptr(out), B, H, W, Cout,
-                                  taps, float(scale), stream()))
+                                  taps, float(scale), _lib.ptr(scratch), stream()))
     torch.cuda.synchronize()
     return nchw(out)
 

@@ -62,6 +62,39 @@ def test_conv2d(G, case):
     assert C.rel_l2(got, ref) < TOL
 
 
+SPLITK_CASES = [
+    (8, 4, 4, 256, 256, 256, 3, True, True, True, 0.70710678),    # level-6 up block (K = 4608 over 2 tiles)
+    (8, 8, 8, 256, 0, 256, 3, True, False, False, 1.0),
+    (2, 16, 16, 512, 0, 256, 1, True, False, True, 1.0),         # 1x1 shortcut on concat width
+    (3, 6, 6, 128, 64, 192, 3, False, True, False, 1.0),         # ragged: M, K, N all off the tile grid
+    (8, 32, 32, 256, 0, 256, 3, True, True, True, 0.70710678),
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_conv2d_splitk(G, case):
+    B, H, W, C1, C2, Cout, k, has_b, has_b2, has_res, scale = case
+    x1 = rnd(1, (B, C1, H, W))
+    x2 = rnd(2, (B, C2, H, W)) if C2 else None
+    w = rnd(3, (Cout, C1 + C2, k, k), (1.0 / ((C1 + C2) * k * k)) ** 0.5)
+    bias = rnd(4, (Cout,), 0.1) if has_b else None
+    bias2 = rnd(5, (B, Cout + 8), 0.1) if has_b2 else None
+    res = rnd(6, (B, Cout, H, W)) if has_res else None
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    ref = F.conv2d(xin, w, bias, padding=k // 2)
+    if has_b2:
+        ref = ref + bias2[:, :Cout, None, None]
+    if has_res:
+        ref = ref + res
+    ref = ref * scale
+    got = G.conv2d(x1, w, bias, x2, bias2, res, scale, splitk=True)
+    assert G.conv2d.last_split, "policy did not split this shape"
+    assert C.rel_l2(got, ref) < TOL
+    # split-K must agree with the single-pass kernel to rounding
+    single = G.conv2d(x1, w, bias, x2, bias2, res, scale)
+    assert C.rel_l2(got, single) < 5e-6
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 16, 8), (1, 128, 32, 32), (2, 16, 8, 8), (1, 512, 4, 4),
                                    (1, 256, 64, 64)])
 @pytest.mark.parametrize("silu", [True, False])

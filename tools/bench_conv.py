@@ -40,10 +40,12 @@ def run(shape, iters=5, check=False):
     res = torch.randn(B, H, W, Cout, generator=g).cuda()
     out = torch.empty(B, H, W, Cout, device="cuda")
     st = _lib.current_stream()
+    nscr = L.flowse_op_conv2d_scratch_floats(B, H, W, C1 + C2, Cout, taps)
+    scratch = torch.empty(max(nscr, 1), device="cuda")
 
     def call():
         _lib.check(L.flowse_op_conv2d(_lib.ptr(a1), C1, _lib.ptr(a2), C2, _lib.ptr(w), _lib.ptr(bias), None, 0,
-                                      _lib.ptr(res), _lib.ptr(out), B, H, W, Cout, taps, 0.7071, st))
+                                      _lib.ptr(res), _lib.ptr(out), B, H, W, Cout, taps, 0.7071, _lib.ptr(scratch), st))
     call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
