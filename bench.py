@@ -170,11 +170,21 @@ def main():
         dom = prof.get("conv_mfma_128x128")
         if dom and dom["ms"] > 0:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "flowse::conv_mfma_kernel<2,2,2,2> (fp32 implicit-GEMM conv)",
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            if os.path.exists(tpath) and (B, T, NS) == (8, 256, 5):      # PMC passes were taken on this workload
+                tj = json.load(open(tpath))
+                k = tj.get("dominant_kernel")
+                if k:
+                    traffic = tj["kernels"][k]["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes)"
+            out["roofline"] = {"bound": "mfma",
+                               "kernel": "flowse::conv_mfma_fast_kernel<2,2,2,2> (fp32 implicit-GEMM conv, 128x128 tile)",
                                "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                               "frac": ach / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                                "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                                "flops_per_launch_avg": dom["flops"] / dom["launches"],
+                               "algorithmic_bytes_per_launch_avg": dom["bytes"] / dom["launches"],
                                "time_share_of_step": dom["ms"] * 1e-3 / elapsed}
         if args.profile_all:
             model.dnn.profile_begin(1)

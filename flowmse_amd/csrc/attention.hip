@@ -5,7 +5,8 @@
 //     w = softmax_j( sum_c q[b,c,i] k[b,c,j] * C^-1/2 );  h[b,c,i] = sum_j w[i,j] v[b,c,j]
 // q, k, v arrive token-major from one fused 1x1 projection: qkv[b][token][q(0:C) | k(C:2C) | v(2C:3C)].
 //
-// Flash-style, one wave per 32-query tile, never materialising the L x L score matrix.  Both products are
+// Flash-style, one 4-wave block per 32-query tile (the key tiles are dealt to the waves, whose online-softmax
+// states are merged through LDS at the end), never materialising the L x L score matrix.  Both products are
 // computed TRANSPOSED so that every per-query quantity (running max, running sum, rescale factor) is
 // lane-local (lane & 31 = query):
 //   S^T[key][query] = K Q^T   A = K rows (key = lane&31),       B = Q rows (query = lane&31)
@@ -19,20 +20,26 @@ namespace flowse {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+constexpr int ATT_WAVES = 4;
+
 template <int NCT>   // C = 32 * NCT
-__global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__ qkv, int L, float* __restrict__ out,
-                                                       float scale) {
+__global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const float* __restrict__ qkv, int L,
+                                                                   float* __restrict__ out, float scale) {
     constexpr int C = 32 * NCT;
     constexpr int QROW = C + 4;
-    __shared__ __attribute__((aligned(16))) float Qs[32 * QROW];
-    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm;                       // [32][QROW]: query tile, later the merged O tile
+    float* sm_m = sm + 32 * QROW;         // [ATT_WAVES][32] running max per wave
+    float* sm_l = sm_m + ATT_WAVES * 32;  // [ATT_WAVES][32] running sum per wave
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int b = blockIdx.y, q0 = blockIdx.x * 32;
     const int64_t rs = 3 * C;                                  // token stride
     const float* base = qkv + (int64_t)b * L * rs;
 
     // stage the query tile (zero rows beyond L)
-    for (int i = lane; i < 32 * (C / 4); i += 64) {
+    for (int i = tid; i < 32 * (C / 4); i += 64 * ATT_WAVES) {
         const int r = i / (C / 4), c4 = i - r * (C / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q0 + r < L) v = *reinterpret_cast<const float4*>(base + (int64_t)(q0 + r) * rs + c4 * 4);
@@ -47,7 +54,8 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int k0 = 0; k0 < L; k0 += 32) {
+    // the key tiles are dealt round-robin to the waves; each wave keeps its own online-softmax state
+    for (int k0 = wave * 32; k0 < L; k0 += 32 * ATT_WAVES) {
         // ---- S^T tile
         f32x16 s;
 #pragma unroll
@@ -58,8 +66,8 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
         const float* qp = Qs + li * QROW + kh * 4;
 #pragma unroll 4
         for (int j = 0; j < C / 8; ++j) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kok) a = *reinterpret_cast<const float4*>(kp + j * 8);
+            float4 a = *reinterpret_cast<const float4*>(kp + j * 8);
+            if (!kok) a = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 q = *reinterpret_cast<const float4*>(qp + j * 8);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q.x, s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q.y, s, 0, 0, 0);
@@ -94,42 +102,76 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                float v = 0.f;
-                if (key < L) v = base[(int64_t)key * rs + 2 * C + t * 32 + li];
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[r], o[t], 0, 0, 0);
+                const float v = base[(int64_t)(key < L ? key : 0) * rs + 2 * C + t * 32 + li];
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(key < L ? v : 0.f, s[r], o[t], 0, 0, 0);
             }
         }
     }
-    // ---- store O[query][channel]: this lane's query = li, channels t*32 + (r&3) + 8(r>>2) + 4kh
-    const int qrow = q0 + li;
-    if (qrow < L) {
-        const float inv = 1.f / l_run;
-        float* op = out + ((int64_t)b * L + qrow) * C;
+    // ---- merge the per-wave states: m = max_w m_w, O = sum_w O_w e^{m_w - m}, l = sum_w l_w e^{m_w - m}
+    if (kh == 0) {
+        sm_m[wave * 32 + li] = m_run;
+        sm_l[wave * 32 + li] = l_run;
+    }
+    __syncthreads();                       // also: every wave is done reading Qs
+    float m_tot = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < NCT; ++t)
+    for (int w = 0; w < ATT_WAVES; ++w) m_tot = fmaxf(m_tot, sm_m[w * 32 + li]);
+    float l_tot = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = t * 32 + 8 * g + 4 * kh;
-                *reinterpret_cast<float4*>(op + c) = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv,
-                                                                 o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
-            }
+    for (int w = 0; w < ATT_WAVES; ++w) l_tot += sm_l[w * 32 + li] * expf(sm_m[w * 32 + li] - m_tot);
+    const float f = expf(m_run - m_tot);   // 0 for a wave that saw no key tile (m_run = -inf)
+    float* Os = Qs;                        // merged O[query][channel], row stride QROW
+#pragma unroll 1
+    for (int w = 0; w < ATT_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NCT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4* p = reinterpret_cast<float4*>(Os + li * QROW + t * 32 + 8 * g + 4 * kh);
+                    float4 v = make_float4(o[t][4 * g] * f, o[t][4 * g + 1] * f, o[t][4 * g + 2] * f,
+                                           o[t][4 * g + 3] * f);
+                    if (w > 0) {
+                        const float4 old = *p;
+                        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                    }
+                    *p = v;
+                }
+        }
+        __syncthreads();
+    }
+    if (kh == 0 && wave == 0) sm_l[li] = l_tot;     // wave 0 of sm_l is free now: broadcast 1/l to all threads
+    __syncthreads();
+    for (int i = tid; i < 32 * (C / 4); i += 64 * ATT_WAVES) {
+        const int r = i / (C / 4), c4 = i - r * (C / 4);
+        if (q0 + r >= L) continue;
+        const float inv = 1.f / sm_l[r];
+        const float4 v = *reinterpret_cast<const float4*>(Os + r * QROW + c4 * 4);
+        *reinterpret_cast<float4*>(out + ((int64_t)b * L + q0 + r) * C + c4 * 4) =
+            make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
     }
 }
 
+template <int NCT>
+static int launch_att(const float* qkv, int B, int L, float* out, hipStream_t s) {
+    constexpr int C = 32 * NCT;
+    const size_t lds = (32 * (C + 4) + 2 * ATT_WAVES * 32) * sizeof(float);
+    const dim3 grid((L + 31) / 32, B), block(64 * ATT_WAVES);
+    hipLaunchKernelGGL(attention_kernel<NCT>, grid, block, lds, s, qkv, L, out, 1.0f / sqrtf((float)C));
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
 int launch_attention(const float* qkv, int B, int L, int C, float* out, hipStream_t s) {
-    const dim3 grid((L + 31) / 32, B), block(64);
-    const float scale = 1.0f / sqrtf((float)C);
     switch (C) {
-        case 32:  hipLaunchKernelGGL(attention_kernel<1>, grid, block, 0, s, qkv, L, out, scale); break;
-        case 64:  hipLaunchKernelGGL(attention_kernel<2>, grid, block, 0, s, qkv, L, out, scale); break;
-        case 128: hipLaunchKernelGGL(attention_kernel<4>, grid, block, 0, s, qkv, L, out, scale); break;
-        case 256: hipLaunchKernelGGL(attention_kernel<8>, grid, block, 0, s, qkv, L, out, scale); break;
+        case 32:  return launch_att<1>(qkv, B, L, out, s);
+        case 64:  return launch_att<2>(qkv, B, L, out, s);
+        case 128: return launch_att<4>(qkv, B, L, out, s);
+        case 256: return launch_att<8>(qkv, B, L, out, s);
         default:
             set_error("attention: unsupported channel count %d (32/64/128/256)", C);
             return ERR_SHAPE;
     }
-    FLOWSE_LAUNCH_CHECK();
-    return OK;
 }
 
 }  // namespace flowse

@@ -54,8 +54,17 @@ struct ConvArgs {
     // tile to `partial` [ksplit][B*H*W][Cout]; splitk_reduce sums the slices and applies the epilogue.
     int ksplit = 1;
     float* partial = nullptr;
+    // fused GroupNorm statistics of the OUTPUT (optional): per-(sample, pixel tile, channel) sum / sum of squares
+    // written to stats[((b * stats_nblk + tile) * Cout + c) * 2 + {0,1}], the layout gn_finalize consumes.
+    // Only honoured when H*W % 128 == 0 and ksplit == 1 (see conv_fused_stats_blocks).
+    float* stats = nullptr;
+    int stats_nblk = 0;
 };
-int launch_conv(const ConvArgs& a, hipStream_t s);
+// number of per-sample partial blocks a conv writes when stats fusion applies to this shape, else 0
+int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps);
+// with_reduce = false: a split-K launch only writes the partial slices (the caller runs launch_splitk_reduce)
+int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce = true);
+int launch_splitk_reduce(const ConvArgs& a, hipStream_t s);
 // number of K slices launch_conv will use for this shape (1 = no split) and the partial-buffer size in floats
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps);
 
@@ -67,9 +76,11 @@ int launch_conv_cin4(const ConvArgs& a, hipStream_t s);
 int gn_partial_blocks(int HW, int C);
 int launch_gn_stats(const float* in1, int C1, const float* in2, int C2, int B, int HW,
                     float* partial /*[B][nblk][C][2]*/, int nblk, hipStream_t s);
-int launch_gn_finalize(const float* partial, int nblk, int B, int HW, int C, int G,
-                       const float* gamma, float eps, float* mean /*[B][C]*/, float* scale /*[B][C]*/,
-                       hipStream_t s);
+// statistics may come as two partial sets (channel concat of two tensors whose partials were produced
+// separately, e.g. by their conv epilogues): set 1 covers channels [0,C1), set 2 channels [C1, C1+C2)
+int launch_gn_finalize(const float* partial1, int nblk1, int C1, const float* partial2, int nblk2, int C2, int B,
+                       int HW, int G, const float* gamma, float eps, float* mean /*[B][C]*/,
+                       float* scale /*[B][C]*/, hipStream_t s);
 int launch_gn_apply(const float* in1, int C1, const float* in2, int C2, int B, int HW,
                     GnParams gn, int silu, float* out, hipStream_t s);
 

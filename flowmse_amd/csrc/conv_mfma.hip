@@ -27,6 +27,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KC = 32;          // channels per K step
 constexpr int LDS_ROW = 36;     // floats per LDS tile row (KC + 4 pad)
 
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with its own
+// L2); remapping so that every XCD walks a CONTIGUOUS range of tiles keeps the rows shared by vertically
+// adjacent pixel tiles (the 3x3 halo) and the N tiles of one pixel tile in one L2.  Bijective for any grid size.
+// Placement is a speed matter only -- nothing depends on it for correctness.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ---- shared epilogue.  The accumulators go through LDS (C/D layout of the 32x32 MFMA: col = lane & 31,
 // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) so that bias / per-sample bias / residual are read and the result
 // is written as coalesced float4 rows of the NHWC output.  Precondition: all waves are past their last LDS read.
@@ -71,6 +81,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + n);
         const bool has_b2 = a.bias2 != nullptr, has_res = a.res != nullptr;
+        float4 st_s = make_float4(0.f, 0.f, 0.f, 0.f), st_q = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
         for (int rr = er0; rr < BM; rr += RPP) {
             const int m = m0 + rr;
@@ -88,6 +99,35 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
             }
             v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
             *reinterpret_cast<float4*>(a.out + o) = v;
+            st_s.x += v.x; st_s.y += v.y; st_s.z += v.z; st_s.w += v.w;
+            st_q.x = fmaf(v.x, v.x, st_q.x); st_q.y = fmaf(v.y, v.y, st_q.y);
+            st_q.z = fmaf(v.z, v.z, st_q.z); st_q.w = fmaf(v.w, v.w, st_q.w);
+        }
+        if (a.stats) {
+            // Fused GroupNorm statistics of the tile just written (launch guarantees: tile inside one sample, all
+            // BM rows valid).  Threads tid and tid+32 of a wave own the same channel quad when C4 == 32; in general
+            // threads with equal ec4 are reduced through the free tail of the LDS block.
+            float* red = smem + BM * CROW;                       // [NT / C4][C4][8] floats
+            float* mine = red + (er0 * C4 + ec4) * 8;
+            mine[0] = st_s.x; mine[1] = st_s.y; mine[2] = st_s.z; mine[3] = st_s.w;
+            mine[4] = st_q.x; mine[5] = st_q.y; mine[6] = st_q.z; mine[7] = st_q.w;
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        if (n < a.Cout && er0 == 0) {
+            const float* red = smem + BM * CROW;
+            float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < RPP; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc8[j] += red[(r * C4 + ec4) * 8 + j];
+            const int bsmp = m0 / HW, tile = (m0 - bsmp * HW) / BM;
+            float* dst = a.stats + (((int64_t)bsmp * a.stats_nblk + tile) * a.Cout + n) * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dst[2 * j] = acc8[j];
+                dst[2 * j + 1] = acc8[4 + j];
+            }
         }
     }
 }
@@ -107,7 +147,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs a) 
     const int Cin = a.C1 + a.C2;
     const int taps = a.taps;
     const int n_ntiles = (a.Cout + BN - 1) / BN;
-    const int mt = blockIdx.x / n_ntiles, nt = blockIdx.x - mt * n_ntiles;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
     const int split = blockIdx.y;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -267,7 +308,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
     const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
     const int taps = a.taps;
     const int n_ntiles = (a.Cout + BN - 1) / BN;
-    const int mt = blockIdx.x / n_ntiles, nt = blockIdx.x - mt * n_ntiles;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
     const int split = blockIdx.y;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -403,7 +445,10 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int grid = (int)((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-    const size_t lds = 2 * (BM + BN) * LDS_ROW * sizeof(float);
+    // staging buffers; the epilogue's C tile + stats scratch (NT*8 floats) must fit as well
+    const size_t lds_stage = 2 * (BM + BN) * LDS_ROW * sizeof(float);
+    const size_t lds_epi = ((size_t)BM * (BN + 4) + 64 * WM * WN * 8) * sizeof(float);
+    const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static bool attr_done = false;
     if (!attr_done) {
         FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN>),
@@ -456,6 +501,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, int64_t 
 
 // Split-K policy: images so small that the 128x128 tiling yields < 256 blocks (one per CU) are sliced along K
 // until ~512 blocks exist, keeping >= 4 K steps per slice.
+int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps) {
+    const int HW = H * W;
+    if ((HW % 128) != 0 || (Cout & 3) || conv_ksplit(B, H, W, Cin, Cout, taps) != 1) return 0;
+    return HW / 128;
+}
+
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     if (Cout <= 64) return 1;
     const int64_t M = (int64_t)B * H * W;
@@ -472,7 +523,16 @@ int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     return (int)ks;
 }
 
-int launch_conv(const ConvArgs& a, hipStream_t s) {
+int launch_splitk_reduce(const ConvArgs& a, hipStream_t s) {
+    const int64_t total4 = (int64_t)a.B * a.H * a.W * (a.Cout / 4);
+    int64_t blocks = (total4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, a, total4);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
     if ((a.C1 & 3) || (a.C2 & 3) || (a.Cout & 3) || (a.bias2 && (a.bias2_stride & 3)) || (a.taps != 1 && a.taps != 9) ||
         a.C1 <= 0 || (a.in2 == nullptr && a.C2 != 0)) {
         set_error("conv: unsupported channel counts C1=%d C2=%d taps=%d", a.C1, a.C2, a.taps);
@@ -490,13 +550,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
             return ERR_ARG;
         }
         const int rc = launch_cfg<2, 2, 2, 2>(a, s);
-        if (rc != OK) return rc;
-        const int64_t total4 = (int64_t)a.B * a.H * a.W * (a.Cout / 4);
-        int64_t blocks = (total4 + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, a, total4);
-        FLOWSE_LAUNCH_CHECK();
-        return OK;
+        if (rc != OK || !with_reduce) return rc;
+        return launch_splitk_reduce(a, s);
     }
     return launch_cfg<2, 2, 2, 2>(a, s);
 }

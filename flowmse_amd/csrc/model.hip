@@ -59,6 +59,8 @@ struct Module {
 struct Tn {
     size_t off = 0;
     int B = 0, H = 0, W = 0, C = 0;
+    size_t st_off = 0;      // fused GroupNorm partials written by the producing conv (st_nblk blocks per sample)
+    int st_nblk = 0;
     size_t bytes() const { return (size_t)B * H * W * C * sizeof(float); }
     bool valid() const { return B > 0; }
 };
@@ -460,7 +462,15 @@ struct Builder {
         t.off = arena.alloc(t.bytes());
         return t;
     }
-    void release(const Tn& t) { if (t.valid()) arena.release(t.off); }
+    void release(const Tn& t) {
+        if (!t.valid()) return;
+        arena.release(t.off);
+        if (t.st_nblk > 0) arena.release(t.st_off);
+    }
+    void drop_stats(Tn& t) {          // the tensor was modified in place: its fused statistics are stale
+        if (t.st_nblk > 0) arena.release(t.st_off);
+        t.st_nblk = 0;
+    }
     void op(const std::string& label, std::function<int(hipStream_t)> f, double flops = 0.0, double bytes = 0.0,
             bool dominant = false) {
         plan->ops.push_back(std::move(f));
@@ -470,27 +480,46 @@ struct Builder {
         plan->dominant.push_back(dominant ? 1 : 0);
     }
 
-    // stats + finalize; returns per-(b,c) mean / scale buffers (caller releases)
+    // statistics (fused partials of the producing conv when present, else a gn_stats pass per tensor) +
+    // finalize; returns per-(b,c) mean / scale buffers (caller releases)
     GnBuf gn(const Tn& a, const Tn* b2, int64_t w_gamma, int64_t w_beta) {
         flowse_model* M = m;
         const int C1 = a.C, C2 = b2 ? b2->C : 0, C = C1 + C2, HW = a.H * a.W, Bn = B;
         const int G = std::min(C / 4, 32);
-        const int nblk = gn_partial_blocks(HW, C);
-        const size_t part = arena.alloc((size_t)Bn * nblk * C * 2 * sizeof(float));
+        size_t poff[2] = {0, 0};
+        int pnblk[2] = {0, 0};
+        bool temp[2] = {false, false};
+        const Tn* src[2] = {&a, b2};
+        for (int k = 0; k < 2; ++k) {
+            if (!src[k]) continue;
+            if (src[k]->st_nblk > 0) {
+                poff[k] = src[k]->st_off;
+                pnblk[k] = src[k]->st_nblk;
+                continue;
+            }
+            const int Ck = src[k]->C;
+            const int nblk = gn_partial_blocks(HW, Ck);
+            poff[k] = arena.alloc((size_t)Bn * nblk * Ck * 2 * sizeof(float));
+            pnblk[k] = nblk;
+            temp[k] = true;
+            const size_t t_off = src[k]->off, p_off = poff[k];
+            op("gn_stats", [=](hipStream_t s) {
+                return launch_gn_stats(M->A(t_off), Ck, nullptr, 0, Bn, HW, M->A(p_off), nblk, s);
+            }, 3.0 * Bn * HW * Ck, 4.0 * Bn * HW * Ck);
+        }
         GnBuf g;
         g.mean = arena.alloc((size_t)Bn * C * sizeof(float));
         g.scale = arena.alloc((size_t)Bn * C * sizeof(float));
         g.beta = w_beta;
-        const size_t a_off = a.off, b_off = b2 ? b2->off : 0;
+        const size_t gm = g.mean, gs = g.scale, p0 = poff[0], p1 = poff[1];
+        const int n0 = pnblk[0], n1 = pnblk[1];
         const bool has2 = b2 != nullptr;
-        op("gn_stats", [=](hipStream_t s) {
-            return launch_gn_stats(M->A(a_off), C1, has2 ? M->A(b_off) : nullptr, C2, Bn, HW, M->A(part), nblk, s);
-        }, 3.0 * Bn * HW * C, 4.0 * Bn * HW * C);
-        const size_t gm = g.mean, gs = g.scale;
         op("gn_finalize", [=](hipStream_t s) {
-            return launch_gn_finalize(M->A(part), nblk, Bn, HW, C, G, M->W(w_gamma), 1e-6f, M->A(gm), M->A(gs), s);
+            return launch_gn_finalize(M->A(p0), n0, C1, has2 ? M->A(p1) : nullptr, n1, C2, Bn, HW, G, M->W(w_gamma),
+                                      1e-6f, M->A(gm), M->A(gs), s);
         });
-        arena.release(part);
+        for (int k = 0; k < 2; ++k)
+            if (temp[k]) arena.release(poff[k]);
         return g;
     }
     void gn_release(const GnBuf& g) {
@@ -519,11 +548,17 @@ struct Builder {
         const size_t a_off = a.off, b_off = b2 ? b2->off : 0, o_off = o.off, r_off = res ? res->off : 0;
         const bool has2 = b2 != nullptr, hasres = res != nullptr;
         const int ks = cin4 ? 1 : conv_ksplit(Bn, H, Wd, C1 + C2, Cout, taps);
+        const int st_nblk = (cin4 || out_is_res || Cout < 16) ? 0 : conv_fused_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps);
+        if (st_nblk > 0) {
+            o.st_nblk = st_nblk;
+            o.st_off = arena.alloc((size_t)Bn * st_nblk * Cout * 2 * sizeof(float));
+        }
+        const size_t st_off = o.st_off;
         const size_t part_off = ks > 1 ? arena.alloc((size_t)ks * Bn * H * Wd * Cout * sizeof(float)) : 0;
         const size_t table_off = M_table_off;     // by value: the Builder dies before the plan runs
         const std::string full_label = label + "@" + std::to_string(H) + "x" + std::to_string(Wd) + ":" +
                                        std::to_string(C1 + C2) + ">" + std::to_string(Cout);
-        op(full_label, [=](hipStream_t s) {
+        auto make_args = [=]() {
             ConvArgs c;
             c.in1 = M->A(a_off);
             c.in2 = has2 ? M->A(b_off) : nullptr;
@@ -540,11 +575,21 @@ struct Builder {
             c.scale = scale;
             c.ksplit = ks;
             c.partial = ks > 1 ? M->A(part_off) : nullptr;
-            return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s);
-        },
-           2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2),
-           4.0 * ((double)Bn * H * Wd * (C1 + C2 + Cout * (hasres ? 2 : 1)) + (double)Cout * taps * (C1 + C2)),
-           !cin4 && Cout > 64);
+            c.stats = st_nblk > 0 ? M->A(st_off) : nullptr;
+            c.stats_nblk = st_nblk;
+            return c;
+        };
+        const double flops = 2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2);
+        const double out_bytes = 4.0 * Bn * H * Wd * Cout * (hasres ? 2 : 1);
+        const double in_bytes = 4.0 * ((double)Bn * H * Wd * (C1 + C2) + (double)Cout * taps * (C1 + C2));
+        const double part_bytes = 4.0 * ks * (double)Bn * H * Wd * Cout;
+        op(full_label, [=](hipStream_t s) {
+            const ConvArgs c = make_args();
+            return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s, false);
+        }, flops, in_bytes + (ks > 1 ? part_bytes : out_bytes), !cin4 && Cout > 64);
+        if (ks > 1)
+            op("splitk_reduce", [=](hipStream_t s) { return launch_splitk_reduce(make_args(), s); }, 0.0,
+               part_bytes + out_bytes);
         if (ks > 1) arena.release(part_off);
         return o;
     }
@@ -692,6 +737,7 @@ static int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
             ipyr = ip2;
             const Module& cb = next();
             bd.conv("combine_1x1", ipyr, nullptr, cb.w_a, cb.w_a_b, -1, cb.out_ch, 1, &h, 1.f, true, true);
+            bd.drop_stats(h);          // h was updated in place
             hs.push_back(h);
         }
     }
@@ -1098,7 +1144,7 @@ int flowse_op_group_norm(const float* in1, int C1, const float* in2, int C2, con
     float* scl = mean + (int64_t)B * C;
     int rc = launch_gn_stats(in1, C1, in2, C2, B, HW, part, nblk, s);
     if (rc != OK) return rc;
-    rc = launch_gn_finalize(part, nblk, B, HW, C, G, gamma, eps, mean, scl, s);
+    rc = launch_gn_finalize(part, nblk, C, nullptr, 0, 0, B, HW, G, gamma, eps, mean, scl, s);
     if (rc != OK) return rc;
     GnParams p{mean, scl, beta};
     return launch_gn_apply(in1, C1, in2, C2, B, HW, p, silu, out, s);

@@ -71,19 +71,25 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __res
     }
 }
 
-// grid (G, B), 64 threads.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nblk, int HW, int C,
+// grid (G, B), 64 threads.  Channels [0,C1) take their partials from set 1, [C1,C1+C2) from set 2.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ p1, int nblk1, int C1,
+                                                         const float* __restrict__ p2, int nblk2, int C2, int HW,
                                                          int G, const float* __restrict__ gamma, float eps,
                                                          float* __restrict__ mean, float* __restrict__ scale) {
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int C = C1 + C2;
     const int cpg = C / G;
-    const int n = nblk * cpg;
     double s = 0.0, ss = 0.0;
-    for (int i = lane; i < n; i += 64) {
-        const int blk = i / cpg, c = g * cpg + (i - blk * cpg);
-        const float* p = partial + (((int64_t)b * nblk + blk) * C + c) * 2;
-        s += (double)p[0];
-        ss += (double)p[1];
+    for (int j = 0; j < cpg; ++j) {
+        const int c = g * cpg + j;
+        const bool first = c < C1;
+        const float* p = first ? p1 : p2;
+        const int nblk = first ? nblk1 : nblk2, Cs = first ? C1 : C2, cc = first ? c : c - C1;
+        for (int blk = lane; blk < nblk; blk += 64) {
+            const float* q = p + (((int64_t)b * nblk + blk) * Cs + cc) * 2;
+            s += (double)q[0];
+            ss += (double)q[1];
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -143,14 +149,15 @@ int launch_gn_stats(const float* in1, int C1, const float* in2, int C2, int B, i
     return OK;
 }
 
-int launch_gn_finalize(const float* partial, int nblk, int B, int HW, int C, int G, const float* gamma, float eps,
-                       float* mean, float* scale, hipStream_t s) {
-    if (C % G != 0 || C / G > 64) {
+int launch_gn_finalize(const float* partial1, int nblk1, int C1, const float* partial2, int nblk2, int C2, int B,
+                       int HW, int G, const float* gamma, float eps, float* mean, float* scale, hipStream_t s) {
+    const int C = C1 + C2;
+    if (C % G != 0 || C / G > 64 || (C2 > 0 && !partial2)) {
         set_error("gn_finalize: unsupported C=%d G=%d", C, G);
         return ERR_SHAPE;
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial, nblk, HW, C, G, gamma, eps, mean,
-                       scale);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial1, nblk1, C1, partial2, nblk2, C2, HW, G,
+                       gamma, eps, mean, scale);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
