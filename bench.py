@@ -47,6 +47,13 @@ def cpu_baseline(sd, nsolver, frames, reps, budget_s=60.0):
         logical = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    quota = None
+    try:                                     # cgroup v2 CPU quota of the container, if any
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(per)
+    except Exception:
+        pass
     cfg = O.make_cfg()
     t_start = time.perf_counter()
 
@@ -74,7 +81,8 @@ def cpu_baseline(sd, nsolver, frames, reps, budget_s=60.0):
     times = nfe_time(frames, reps + 1)[1:]
     t_nfe = sorted(times)[len(times) // 2]
     return {"value": frames / (nsolver * t_nfe), "unit": "frames/s", "cores": best_n, "kind": "port",
-            "host_logical_cpus": logical, "thread_sweep_s_per_nfe_at_64_frames": sweep,
+            "host_logical_cpus": logical, "cgroup_cpu_quota": quota,
+            "thread_sweep_s_per_nfe_at_64_frames": sweep,
             "sample": f"oracle (torch-CPU fp32 restatement of the reference path) on 1 utterance [1,1,256,{frames}], "
                       f"1 Euler step = 1 NFE, median of {reps} after 1 warm-up = {t_nfe:.3f} s/NFE with "
                       f"{best_n} torch threads (best of the sweep), scaled to N={nsolver} steps "
@@ -167,7 +175,7 @@ def main():
         "achieved_TFLOPs_whole_path": value * NS * FLOP_PER_FRAME_NFE / world / 1e12,
     }
     if rank == 0:
-        dom = prof.get("conv_mfma_128x128")
+        dom = prof.get("conv3x3_halo_gn_128x128")
         if dom and dom["ms"] > 0:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
@@ -179,7 +187,8 @@ def main():
                     traffic = tj["kernels"][k]["hbm_bytes_per_launch"]
                     traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes)"
             out["roofline"] = {"bound": "mfma",
-                               "kernel": "flowse::conv_mfma_fast_kernel<2,2,2,2> (fp32 implicit-GEMM conv, 128x128 tile)",
+                               "kernel": "flowse::conv3x3_halo_kernel<2,2,2,2,true> (fp32 implicit-GEMM 3x3 conv, 128x128 tile, "
+                                         "LDS halo, fused GroupNorm+SiLU input)",
                                "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                                "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],

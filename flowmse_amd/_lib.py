@@ -54,6 +54,7 @@ SIGNATURES = {
     "flowse_upfirdn2d": (_i, [_fp, _fp] + [_i] * 13 + [_fp, _i, _i, _vp]),
     "flowse_op_conv2d": (_i, [_fp, _i, _fp, _i, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _vp]),
     "flowse_op_conv2d_scratch_floats": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "flowse_op_conv3x3_gn": (_i, [_fp, _i, _fp, _i, _fp, _fp, _f, _i, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _fp, _vp]),
     "flowse_op_group_norm_scratch_floats": (_i64, [_i, _i, _i]),
     "flowse_op_group_norm": (_i, [_fp, _i, _fp, _i, _fp, _fp, _f, _i, _fp, _i, _i, _i, _fp, _vp]),
     "flowse_op_fir_up": (_i, [_fp, _fp, _i, _i, _i, _i, _vp]),

@@ -59,7 +59,14 @@ struct ConvArgs {
     // Only honoured when H*W % 128 == 0 and ksplit == 1 (see conv_fused_stats_blocks).
     float* stats = nullptr;
     int stats_nblk = 0;
+    // fused GroupNorm(+SiLU) on the INPUT (optional; only the halo-tile 3x3 kernel applies it, see
+    // conv_supports_fused_gn): A = act((x - mean[b][c]) * scale[b][c] + beta[c]) with c the concat channel index
+    GnParams gn = {nullptr, nullptr, nullptr};
+    int gn_silu = 0;
 };
+// true when launch_conv will run the LDS-halo 3x3 kernel for this shape (the only one that can normalise its
+// input on the fly)
+bool conv_supports_fused_gn(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // number of per-sample partial blocks a conv writes when stats fusion applies to this shape, else 0
 int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps);
 // with_reduce = false: a split-K launch only writes the partial slices (the caller runs launch_splitk_reduce)

@@ -42,7 +42,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // is written as coalesced float4 rows of the NHWC output.  Precondition: all waves are past their last LDS read.
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
-                                              int M, int HW, int split) {
+                                              int M, int HW, int split, int rowW = 0) {
+    // rowW == 0: tile row rr is flat pixel m0 + rr; rowW > 0: the tile is 8 x 16 pixels of an image with row
+    // pitch rowW, m0 = its top-left pixel
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -69,7 +71,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         if (n < a.Cout) {
             float* dst = a.partial + (int64_t)split * M * a.Cout;
             for (int rr = er0; rr < BM; rr += RPP) {
-                const int m = m0 + rr;
+                const int m = rowW ? m0 + (rr >> 4) * rowW + (rr & 15) : m0 + rr;
                 if (m >= M) break;
                 *reinterpret_cast<float4*>(dst + (int64_t)m * a.Cout + n) =
                     *reinterpret_cast<const float4*>(Cs + rr * CROW + ec4 * 4);
@@ -84,7 +86,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         float4 st_s = make_float4(0.f, 0.f, 0.f, 0.f), st_q = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
         for (int rr = er0; rr < BM; rr += RPP) {
-            const int m = m0 + rr;
+            const int m = rowW ? m0 + (rr >> 4) * rowW + (rr & 15) : m0 + rr;
             if (m >= M) break;
             float4 v = *reinterpret_cast<const float4*>(Cs + rr * CROW + ec4 * 4);
             v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
@@ -121,7 +123,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
             for (int r = 0; r < RPP; ++r)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc8[j] += red[(r * C4 + ec4) * 8 + j];
-            const int bsmp = m0 / HW, tile = (m0 - bsmp * HW) / BM;
+            const int bsmp = m0 / HW;
+            int tile = (m0 - bsmp * HW) / BM;
+            if (rowW) {                       // 8x16 tiles, row-major over the image
+                const int rem = m0 - bsmp * HW;
+                tile = ((rem / rowW) >> 3) * (rowW >> 4) + ((rem % rowW) >> 4);
+            }
             float* dst = a.stats + (((int64_t)bsmp * a.stats_nblk + tile) * a.Cout + n) * 2;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -437,6 +444,195 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
     conv_epilogue<WM, WN, TM, TN>(a, acc, smem, m0, n0, M, HW, split);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3x3 convolution with an LDS-resident halo tile (the production kernel for H, W >= 64).
+//
+// The block owns an 8 x 16 pixel tile of one image and BN output channels.  For each 32-channel chunk the
+// (8+2) x (16+2) input halo is staged into LDS ONCE and all nine taps read their shifted A fragments from it
+// (tap = a constant row offset into the halo), so the activation crosses L2 -> LDS once per chunk instead of
+// nine times, and only the per-tap weight tile is streamed per step.  Because every input element is staged
+// exactly once per block, the GroupNorm + SiLU of the consuming ResnetBlock (layerspp.py:246,265: Conv(act(GN(x))))
+// is applied right there, on the way into LDS -- the normalised tensor never exists in HBM.  Zero padding stays
+// exact: out-of-image halo pixels are written as 0 AFTER the activation.
+template <int WM, int WN, int TM, int TN, bool GN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(ConvArgs a) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
+    static_assert(BM == 128 && NT == 256, "8x16 pixel tile, 4 waves");
+    constexpr int HROWS = 180;                          // 10 x 18 halo pixels
+    constexpr int H_LOADS = (HROWS * 8 + NT - 1) / NT;  // 6 float4 per thread
+    constexpr int B_LOADS = (BN * 8 + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                                   // [HROWS][LDS_ROW]
+    float* Bs = smem + HROWS * LDS_ROW;                 // [2][BN][LDS_ROW]
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int M = a.B * HW;
+    const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
+    const int n_ntiles = (a.Cout + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
+    const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 3);
+    const int b = mt / tiles_img, tt = mt - b * tiles_img;
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int y0 = ty * 8, x0 = tx * 16, n0 = nt * BN;
+    const int m_tl = (b * H + y0) * W + x0;              // top-left output pixel
+
+    const int col4 = tid & 7, row0 = tid >> 3;
+    unsigned hvo1[H_LOADS], hvo2[H_LOADS];
+    unsigned hin = 0;                                    // bit q: halo row q of this thread lies inside the image
+#pragma unroll
+    for (int q = 0; q < H_LOADS; ++q) {
+        const int hr = row0 + 32 * q;
+        const int hy = hr / 18, hx = hr - hy * 18;
+        const bool in = hr < HROWS && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+        hvo1[q] = in ? (unsigned)((hy * W + hx) * C1 + col4 * 4) * 4u : OOB;
+        hvo2[q] = in ? (unsigned)((hy * W + hx) * C2 + col4 * 4) * 4u : OOB;
+        hin |= in ? (1u << q) : 0u;
+    }
+    unsigned bvo[B_LOADS];
+#pragma unroll
+    for (int q = 0; q < B_LOADS; ++q) {
+        const int r = row0 + 32 * q;
+        const int n = n0 + r;
+        bvo[q] = (r < BN && n < a.Cout) ? (unsigned)(n * 9 * Cin + col4 * 4) * 4u : OOB;
+    }
+    const int64_t wbase = (int64_t)m_tl - W - 1;         // window origin = halo pixel (0,0)
+    const int wpix = 9 * W + 18;
+    const __amdgpu_buffer_rsrc_t rsrc1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1 + wbase * C1), 0, wpix * C1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(C2 ? a.in2 + wbase * C2 : a.in1), 0, C2 ? wpix * C2 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.Cout * 9 * Cin * 4, 0x00020000);
+
+    u32x4 rh[H_LOADS], rb[B_LOADS];
+    float4 g_mu, g_sc, g_be;                             // GroupNorm parameters of the staged channel quad
+
+    auto gloadH = [&](int chunk) {
+        const int c0 = chunk * KC;
+        const bool second = c0 >= C1;
+        const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * 4u;
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q)
+            rh[q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, hvo2[q], soff, 0)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, hvo1[q], soff, 0);
+        if (GN) {
+            const int cg = c0 + col4 * 4;
+            g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
+            g_sc = *reinterpret_cast<const float4*>(a.gn.scale + (int64_t)b * Cin + cg);
+            g_be = *reinterpret_cast<const float4*>(a.gn.beta + cg);
+        }
+    };
+    // GroupNorm + SiLU on the staged registers (VALU only; runs under the partner wave's MFMAs), then the plain
+    // LDS write once every wave has left the previous chunk's halo.  v_exp / v_rcp based SiLU: ~2 ulp.
+    auto xformH = [&]() {
+        if (!GN) return;
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            const bool in = (hin >> q) & 1u;
+            float4 v;
+            v.x = __uint_as_float(rh[q].x); v.y = __uint_as_float(rh[q].y);
+            v.z = __uint_as_float(rh[q].z); v.w = __uint_as_float(rh[q].w);
+            v.x = fmaf(v.x - g_mu.x, g_sc.x, g_be.x); v.y = fmaf(v.y - g_mu.y, g_sc.y, g_be.y);
+            v.z = fmaf(v.z - g_mu.z, g_sc.z, g_be.z); v.w = fmaf(v.w - g_mu.w, g_sc.w, g_be.w);
+            if (a.gn_silu) {
+                v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
+                v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
+            }
+            rh[q].x = in ? __float_as_uint(v.x) : 0u; rh[q].y = in ? __float_as_uint(v.y) : 0u;
+            rh[q].z = in ? __float_as_uint(v.z) : 0u; rh[q].w = in ? __float_as_uint(v.w) : 0u;
+        }
+    };
+    auto lstoreH = [&]() {
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            const int hr = row0 + 32 * q;
+            if (hr < HROWS) *reinterpret_cast<u32x4*>(Hs + hr * LDS_ROW + col4 * 4) = rh[q];
+        }
+    };
+    auto gloadB = [&](int s) {
+        const int chunk = s / 9, tap = s - chunk * 9;
+        const unsigned soff_b = (unsigned)(tap * Cin + chunk * KC) * 4u;
+#pragma unroll
+        for (int q = 0; q < B_LOADS; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo[q], soff_b, 0);
+    };
+    auto lstoreB = [&](int buf) {
+        float* Bb = Bs + buf * BN * LDS_ROW;
+#pragma unroll
+        for (int q = 0; q < B_LOADS; ++q) {
+            const int r = row0 + 32 * q;
+            if (r < BN) *reinterpret_cast<u32x4*>(Bb + r * LDS_ROW + col4 * 4) = rb[q];
+        }
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, kh = lane >> 5;
+    // MFMA tile i of this wave covers tile rows 2*(wm*TM+i), +1; this lane's pixel inside it:
+    int abase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int py = 2 * (wm * TM + i) + (li >> 4), px = li & 15;
+        abase[i] = ((py + 1) * 18 + px + 1) * LDS_ROW + kh * 4;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = Cin / KC;
+    const int S_all = nchunks * 9;
+
+    gloadH(0);
+    gloadB(0);
+    xformH();
+    lstoreH();
+    lstoreB(0);
+    __syncthreads();
+
+    for (int s = 0; s < S_all; ++s) {
+        const int chunk = s / 9, tap = s - chunk * 9;
+        const int buf = s & 1;
+        const bool next_chunk = chunk + 1 < nchunks;
+        if (s + 1 < S_all) gloadB(s + 1);
+        if (tap == 7 && next_chunk) gloadH(chunk + 1);         // one step early; lands under a step of MFMA
+        if (tap == 8 && next_chunk) xformH();                  // normalise in registers before this step's MFMAs
+        const int tapoff = ((tap / 3 - 1) * 18 + (tap - (tap / 3) * 3 - 1)) * LDS_ROW;
+        const float* Bb = Bs + buf * BN * LDS_ROW + (wn * TN * 32 + li) * LDS_ROW + kh * 4;
+#pragma unroll
+        for (int j = 0; j < KC / 8; ++j) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Hs + abase[i] + tapoff + j * 8);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                bf[i] = *reinterpret_cast<const float4*>(Bb + i * 32 * LDS_ROW + j * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[jn].x, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[jn].y, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[jn].z, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[jn].w, acc[i][jn], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < S_all) lstoreB(buf ^ 1);
+        __syncthreads();
+        if (tap == 8 && next_chunk) {                           // everyone is done with this chunk's halo
+            lstoreH();
+            __syncthreads();
+        }
+    }
+    conv_epilogue<WM, WN, TM, TN>(a, acc, smem, m_tl, n0, M, HW, 0, W);
+}
+
 // test hook: FLOWSE_FORCE_GENERIC_CONV=1 routes every shape through the generic gather kernel
 static const bool g_force_generic = getenv("FLOWSE_FORCE_GENERIC_CONV") != nullptr;
 
@@ -523,6 +719,40 @@ int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     return (int)ks;
 }
 
+static const bool g_no_halo = getenv("FLOWSE_NO_HALO_CONV") != nullptr;
+
+bool conv_supports_fused_gn(int B, int H, int W, int C1, int C2, int Cout, int taps) {
+    if (g_no_halo || g_force_generic) return false;
+    if (taps != 9 || (H & 7) || (W & 15) || (C1 % KC) || (C2 % KC) || (Cout & 3)) return false;
+    if (conv_ksplit(B, H, W, C1 + C2, Cout, taps) != 1) return false;
+    const int64_t cmax = C1 > C2 ? C1 : C2;
+    return (int64_t)(9 * W + 18) * cmax * 4 < (1LL << 31) && (int64_t)Cout * 9 * (C1 + C2) * 4 < (1LL << 31);
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_halo(const ConvArgs& a, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int64_t M = (int64_t)a.B * a.H * a.W;
+    const int grid = (int)(M / BM) * ((a.Cout + BN - 1) / BN);
+    const size_t lds_stage = (180 + 2 * BN) * LDS_ROW * sizeof(float);
+    const size_t lds_epi = ((size_t)BM * (BN + 4) + 64 * WM * WN * 8) * sizeof(float);
+    const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    static bool attr_done = false;
+    if (!attr_done) {
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, TM, TN, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, TM, TN, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    if (a.gn.mean)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, TM, TN, true>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    else
+        hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, TM, TN, false>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
 int launch_splitk_reduce(const ConvArgs& a, hipStream_t s) {
     const int64_t total4 = (int64_t)a.B * a.H * a.W * (a.Cout / 4);
     int64_t blocks = (total4 + 255) / 256;
@@ -541,6 +771,15 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
     if ((int64_t)a.B * a.H * a.W >= (1LL << 31) / 4) {
         set_error("conv: too many pixels for 32-bit pixel indices");
         return ERR_SHAPE;
+    }
+    if (a.ksplit <= 1 && conv_supports_fused_gn(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
+        if (a.Cout <= 32) return launch_halo<4, 1, 1, 1>(a, s);
+        if (a.Cout <= 64) return launch_halo<2, 2, 2, 1>(a, s);
+        return launch_halo<2, 2, 2, 2>(a, s);
+    }
+    if (a.gn.mean) {
+        set_error("conv: fused GroupNorm input requested for a shape the halo kernel does not cover");
+        return ERR_ARG;
     }
     if (a.Cout <= 32) return launch_cfg<4, 1, 1, 1>(a, s);
     if (a.Cout <= 64) return launch_cfg<2, 2, 2, 1>(a, s);

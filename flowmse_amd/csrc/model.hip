@@ -129,7 +129,7 @@ struct Plan {
     std::vector<std::function<int(hipStream_t)>> ops;
     std::vector<std::string> labels;
     std::vector<double> flops, bytes;      // algorithmic work / HBM traffic of each launch
-    std::vector<char> dominant;            // 1 = launches conv_mfma_kernel<2,2,2,2> (the dominant kernel)
+    std::vector<char> dominant;            // 1 = launches conv3x3_halo_kernel<2,2,2,2,true> (the dominant kernel)
 };
 
 struct ProfAcc {
@@ -541,7 +541,8 @@ struct Builder {
     }
     // conv: out (new tensor unless `inplace_res`), res optional
     Tn conv(const std::string& label, const Tn& a, const Tn* b2, int64_t w, int64_t bias, int dense_row0, int Cout,
-            int taps, const Tn* res, float scale, bool out_is_res = false, bool cin4 = false) {
+            int taps, const Tn* res, float scale, bool out_is_res = false, bool cin4 = false,
+            const GnBuf* gin = nullptr, bool gin_silu = false) {
         flowse_model* M = m;
         Tn o = out_is_res ? *res : alloc(a.H, a.W, Cout);
         const int C1 = a.C, C2 = b2 ? b2->C : 0, H = a.H, Wd = a.W, Bn = B;
@@ -554,6 +555,8 @@ struct Builder {
             o.st_off = arena.alloc((size_t)Bn * st_nblk * Cout * 2 * sizeof(float));
         }
         const size_t st_off = o.st_off;
+        const bool has_gin = gin != nullptr;
+        const GnBuf gbuf = has_gin ? *gin : GnBuf();
         const size_t part_off = ks > 1 ? arena.alloc((size_t)ks * Bn * H * Wd * Cout * sizeof(float)) : 0;
         const size_t table_off = M_table_off;     // by value: the Builder dies before the plan runs
         const std::string full_label = label + "@" + std::to_string(H) + "x" + std::to_string(Wd) + ":" +
@@ -577,6 +580,10 @@ struct Builder {
             c.partial = ks > 1 ? M->A(part_off) : nullptr;
             c.stats = st_nblk > 0 ? M->A(st_off) : nullptr;
             c.stats_nblk = st_nblk;
+            if (has_gin) {
+                c.gn = GnParams{M->A(gbuf.mean), M->A(gbuf.scale), M->W(gbuf.beta)};
+                c.gn_silu = gin_silu ? 1 : 0;
+            }
             return c;
         };
         const double flops = 2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2);
@@ -586,7 +593,7 @@ struct Builder {
         op(full_label, [=](hipStream_t s) {
             const ConvArgs c = make_args();
             return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s, false);
-        }, flops, in_bytes + (ks > 1 ? part_bytes : out_bytes), !cin4 && Cout > 64);
+        }, flops, in_bytes + (ks > 1 ? part_bytes : out_bytes), has_gin && Cout > 64);
         if (ks > 1)
             op("splitk_reduce", [=](hipStream_t s) { return launch_splitk_reduce(make_args(), s); }, 0.0,
                part_bytes + out_bytes);
@@ -618,11 +625,19 @@ struct Builder {
         const float rs2 = 0.70710678118654752440f;
         GnBuf g0 = gn(x1, x2, mod.w_gn0_g, mod.w_gn0_b);
         Tn h1, xs;
+        const int Cx = x1.C + (x2 ? x2->C : 0);
         if (!mod.up && !mod.down) {
-            Tn h0 = gn_apply(x1, x2, g0, true);
-            gn_release(g0);
-            h1 = conv("conv0_3x3", h0, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f);
-            release(h0);
+            if (conv_supports_fused_gn(B, x1.H, x1.W, x1.C, x2 ? x2->C : 0, mod.out_ch, 9)) {
+                // Conv_0(act(GroupNorm_0(x))) in one kernel: the normalised tensor never reaches HBM
+                h1 = conv("conv0_3x3_gn", x1, x2, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f, false,
+                          false, &g0, true);
+                gn_release(g0);
+            } else {
+                Tn h0 = gn_apply(x1, x2, g0, true);
+                gn_release(g0);
+                h1 = conv("conv0_3x3", h0, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f);
+                release(h0);
+            }
             if (mod.shortcut) xs = conv("conv2_1x1", x1, x2, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f);
         } else {
             Tn hr = fir(x1, mod.up, &g0, true, nullptr);
@@ -633,12 +648,21 @@ struct Builder {
             xs = conv("conv2_1x1", xr, nullptr, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f);
             release(xr);
         }
+        (void)Cx;
         GnBuf g1 = gn(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b);
-        Tn h2 = gn_apply(h1, nullptr, g1, true);
-        gn_release(g1);
-        release(h1);
-        Tn out = conv("conv1_3x3", h2, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, xs.valid() ? &xs : &x1, rs2);
-        release(h2);
+        Tn out;
+        if (conv_supports_fused_gn(B, h1.H, h1.W, h1.C, 0, mod.out_ch, 9)) {
+            out = conv("conv1_3x3_gn", h1, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, xs.valid() ? &xs : &x1, rs2,
+                       false, false, &g1, true);
+            gn_release(g1);
+            release(h1);
+        } else {
+            Tn h2 = gn_apply(h1, nullptr, g1, true);
+            gn_release(g1);
+            release(h1);
+            out = conv("conv1_3x3", h2, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, xs.valid() ? &xs : &x1, rs2);
+            release(h2);
+        }
         release(xs);
         return out;
     }
@@ -769,16 +793,18 @@ static int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
         const Module& gnm = next();
         const Module& pcv = next();
         GnBuf g = bd.gn(h, nullptr, gnm.w_a, gnm.w_a_b);
-        Tn ph = bd.gn_apply(h, nullptr, g, true);
-        bd.gn_release(g);
+        const bool pfuse = conv_supports_fused_gn(B, h.H, h.W, h.C, 0, 4, 9);
+        Tn ph = pfuse ? h : bd.gn_apply(h, nullptr, g, true);
+        const GnBuf* pg = pfuse ? &g : nullptr;
         if (!pyr.valid()) {
-            pyr = bd.conv("pyramid_conv", ph, nullptr, pcv.w_a, pcv.w_a_b, -1, 4, 9, nullptr, 1.f);
+            pyr = bd.conv("pyramid_conv", ph, nullptr, pcv.w_a, pcv.w_a_b, -1, 4, 9, nullptr, 1.f, false, false, pg, true);
         } else {
             Tn up = bd.fir(pyr, true, nullptr, false, nullptr);
             bd.release(pyr);
-            pyr = bd.conv("pyramid_conv", ph, nullptr, pcv.w_a, pcv.w_a_b, -1, 4, 9, &up, 1.f, true);
+            pyr = bd.conv("pyramid_conv", ph, nullptr, pcv.w_a, pcv.w_a_b, -1, 4, 9, &up, 1.f, true, false, pg, true);
         }
-        bd.release(ph);
+        bd.gn_release(g);
+        if (!pfuse) bd.release(ph);
         if (lv != 0) {
             Tn h2 = bd.resblock(next(), h, nullptr);
             bd.release(h);
@@ -844,7 +870,7 @@ static int run_plan(flowse_model* m, Plan* p, hipStream_t s) {
         const bool prof = m->prof_mode == 1 || (m->prof_mode == 0 && p->dominant[i]);
         flowse_model::Pending pd;
         if (prof) {
-            const std::string& name = (m->prof_mode == 0) ? std::string("conv_mfma_128x128") : p->labels[i];
+            const std::string& name = (m->prof_mode == 0) ? std::string("conv3x3_halo_gn_128x128") : p->labels[i];
             auto it = m->prof_label_ix.find(name);
             if (it == m->prof_label_ix.end()) {
                 it = m->prof_label_ix.emplace(name, (int)m->prof_labels.size()).first;
@@ -1148,6 +1174,40 @@ int flowse_op_group_norm(const float* in1, int C1, const float* in2, int C2, con
     if (rc != OK) return rc;
     GnParams p{mean, scl, beta};
     return launch_gn_apply(in1, C1, in2, C2, B, HW, p, silu, out, s);
+}
+
+int flowse_op_conv3x3_gn(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
+                         float eps, int silu, const float* w, const float* bias, const float* bias2, int bias2_stride,
+                         const float* res, float* out, int B, int H, int W, int Cout, float scale, float* scratch,
+                         void* stream) {
+    if (!in1 || !gamma || !beta || !w || !out || !scratch) {
+        set_error("flowse_op_conv3x3_gn: null argument");
+        return ERR_ARG;
+    }
+    if (!in2) C2 = 0;
+    if (!conv_supports_fused_gn(B, H, W, C1, C2, Cout, 9)) {
+        set_error("flowse_op_conv3x3_gn: shape B=%d H=%d W=%d C=%d+%d Cout=%d not covered by the halo kernel", B, H, W,
+                  C1, C2, Cout);
+        return ERR_SHAPE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int C = C1 + C2, HW = H * W;
+    const int G = std::min(C / 4, 32);
+    const int nblk = gn_partial_blocks(HW, C);
+    float* part = scratch;
+    float* mean = scratch + (int64_t)B * nblk * C * 2;
+    float* scl = mean + (int64_t)B * C;
+    int rc = launch_gn_stats(in1, C1, in2, C2, B, HW, part, nblk, s);
+    if (rc != OK) return rc;
+    rc = launch_gn_finalize(part, nblk, C, nullptr, 0, 0, B, HW, G, gamma, eps, mean, scl, s);
+    if (rc != OK) return rc;
+    ConvArgs c;
+    c.in1 = in1; c.in2 = in2; c.C1 = C1; c.C2 = C2;
+    c.w = w; c.bias = bias; c.bias2 = bias2; c.bias2_stride = bias2_stride; c.res = res; c.out = out;
+    c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = 9; c.scale = scale;
+    c.gn = GnParams{mean, scl, beta};
+    c.gn_silu = silu;
+    return launch_conv(c, s);
 }
 
 int flowse_op_fir_up(const float* in, float* out, int B, int H, int W, int C, void* stream) {

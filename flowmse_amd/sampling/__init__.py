@@ -13,7 +13,7 @@ import torch
 
 from .odesolvers import ODEsolver, ODEsolverRegistry
 
-__all__ = ["ODEsolverRegistry", "ODEsolver", "get_white_box_solver", "time_grid"]
+__all__ = ["ODEsolverRegistry", "ODEsolver", "get_white_box_solver", "get_black_box_solver", "time_grid"]
 
 
 def time_grid(T_rev, t_eps, N, device="cpu"):
@@ -53,5 +53,40 @@ def get_white_box_solver(odesolver_name, ode, VF_fn, Y, Y_prior=None, T_rev=1.0,
                 vec_t = torch.ones(Y.shape[0], device=Y.device) * t
                 xt = odesolver.update_fn(xt, vec_t, Y, stepsize)
             return xt, N
+
+    return ode_solver
+
+
+def to_flattened_numpy(x):
+    """Flatten a torch tensor and convert it to numpy (sampling/__init__.py:17-19)."""
+    return x.detach().cpu().numpy().reshape((-1,))
+
+
+def from_flattened_numpy(x, shape):
+    """Form a torch tensor with the given shape from a flattened numpy array (sampling/__init__.py:22-24)."""
+    return torch.from_numpy(x.reshape(shape))
+
+
+def get_black_box_solver(ode, VF_fn, y, rtol=1e-5, atol=1e-5, T_rev=1.0, t_eps=0.03, N=30, method="RK45",
+                         device="cuda", z=None, **kwargs):
+    """Adaptive black-box sampler (reference: flowmse/sampling/__init__.py:64-114): scipy ``solve_ivp`` on the
+    flattened complex state from T_rev down to t_eps (NOT to 0), each right-hand side evaluation being one call
+    of ``VF_fn`` (host <-> device round trip per evaluation, as in the reference).  Returns ``(x, nfe)``.
+    ``evaluate.py`` imports but never calls it; provided for API completeness."""
+    from scipy import integrate
+
+    def ode_solver(**solver_kwargs):
+        with torch.no_grad():
+            x = (ode.prior_sampling(y.shape, y, z)[0] if z is not None else ode.prior_sampling(y.shape, y)[0]).to(device)
+
+            def ode_func(t, xf):
+                xt = from_flattened_numpy(xf, y.shape).to(device).type(torch.complex64)
+                vec_t = torch.ones(y.shape[0], device=xt.device) * t
+                return to_flattened_numpy(VF_fn(xt, vec_t, y))
+
+            solution = integrate.solve_ivp(ode_func, (T_rev, t_eps), to_flattened_numpy(x), rtol=rtol, atol=atol,
+                                           method=method, **solver_kwargs)
+            x = torch.tensor(solution.y[:, -1]).reshape(y.shape).to(device).type(torch.complex64)
+            return x, solution.nfev
 
     return ode_solver

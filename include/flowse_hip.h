@@ -107,8 +107,8 @@ int flowse_axpy(const void* x, const void* k, float dt, void* out, int64_t numel
 
 /* ---- in-library kernel timing (used by bench.py for the live roofline figure) -------------------------
  * Between _begin and _end every selected launch of this handle is bracketed by HIP events on the launch
- * stream.  mode 0: only launches of the dominant kernel (conv_mfma_kernel, 128x128 tile), reported under the
- * key "conv_mfma_128x128"; mode 1: every launch, keyed by op label.  _end synchronises on the recorded events
+ * stream.  mode 0: only launches of the dominant kernel (conv3x3_halo_kernel<2,2,2,2,true>: 3x3 conv, 128x128
+ * tile, fused GroupNorm+SiLU input), reported under the key "conv3x3_halo_gn_128x128"; mode 1: every launch, keyed by op label.  _end synchronises on the recorded events
  * and writes a JSON object {label: {"launches", "ms", "flops", "bytes"}} (algorithmic flops / bytes of the
  * bracketed launches) into `json`. */
 int flowse_profile_begin(flowse_model* m, int mode);
@@ -134,6 +134,14 @@ int flowse_op_conv2d(const float* in1, int C1, const float* in2, int C2, const f
  * `splitk_scratch` holds flowse_op_conv2d_scratch_floats(...) floats (0 = this shape never splits); with
  * splitk_scratch == NULL the single-pass kernel is used. */
 int64_t flowse_op_conv2d_scratch_floats(int B, int H, int W, int Cin, int Cout, int taps);
+/* Fused ResnetBlock half:  out = (conv3x3(act(GroupNorm(cat[in1,in2]))) + bias + bias2[b] + res) * scale
+ * (layerspp.py:246-249 / :265-267) with the normalisation + SiLU applied while the input tile is staged into LDS.
+ * Only for shapes the halo kernel covers (H % 8 == 0, W % 16 == 0, C1 % 32 == 0, C2 % 32 == 0, image large
+ * enough not to be split-K): otherwise FLOWSE_ERR_SHAPE.  `scratch`: flowse_op_group_norm_scratch_floats(). */
+int flowse_op_conv3x3_gn(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
+                         float eps, int silu, const float* w, const float* bias, const float* bias2,
+                         int bias2_stride, const float* res, float* out, int B, int H, int W, int Cout, float scale,
+                         float* scratch, void* stream);
 /* GroupNorm(min(C/4,32) groups, eps) [+ SiLU] over cat[in1,in2] (layerspp.py:219,231; ncsnpp.py:337).
  * `scratch` must hold flowse_op_group_norm_scratch_floats(B,H*W,C1+C2) floats. */
 int64_t flowse_op_group_norm_scratch_floats(int B, int HW, int C);

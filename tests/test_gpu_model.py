@@ -159,6 +159,54 @@ def test_full_sampler_vs_oracle_T256(full):
     assert err < TOL
 
 
+@pytest.mark.parametrize("B,T", [(1, 64), (1, 192), (3, 128)])
+def test_full_forward_shapes_vs_oracle(full, B, T):
+    """Smallest legal utterance, a frame count that is not a power of two (W = 192, 96, 48, 24, 12, 6, 3) and an
+    odd batch, with per-sample times spanning the grid ends (t = 0.03 amplifies the head by 33x)."""
+    from oracle import ncsnpp_oracle as O
+    tb = C.param_tables()["full"]
+    w = C.synth_weights(tb["names"], tb["shapes"])
+    x = C.c64(synth.complex_normal(21, T, (B, 1, 256, T), 0.5))
+    y = C.c64(synth.synth_spectrogram(40 + T, B, 256, T))
+    t = torch.tensor([0.03, 1.0, 0.515][:B])
+    ref = O.ncsnpp_forward(w, O.make_cfg(), torch.cat([x, y], 1), t)
+    got = full.dnn(torch.cat([x, y], 1).cuda(), t.cuda())
+    err = C.rel_l2(got.cpu(), ref)
+    print(f"full forward B={B} T={T} rel-L2", err)
+    assert err < TIGHT
+
+
+def test_long_form_T1024(full):
+    """BASELINE config 5 frame count (T = 1024, attention over 1024 tokens): finite, deterministic, and the
+    first 64 frames' receptive-field-free statistic -- batch independence -- holds at this size."""
+    B, T = 2, 1024
+    x = C.c64(synth.complex_normal(22, 1, (B, 1, 256, T), 0.5)).cuda()
+    y = C.c64(synth.synth_spectrogram(77, B, 256, T)).cuda()
+    t = torch.tensor([0.2725, 0.7575], device="cuda")
+    a = full(x, t, y)
+    assert torch.isfinite(torch.view_as_real(a)).all()
+    assert torch.equal(a, full(x, t, y))
+    one = full(x[1:2].contiguous(), t[1:2], y[1:2].contiguous())
+    assert C.rel_l2(one.cpu(), a[1:2].cpu()) < 2e-5
+
+
+def test_black_box_solver_matches_oracle_vf(tiny):
+    """scipy RK45 wrapper over the HIP vector field == the same scipy call over the oracle vector field."""
+    from flowmse_amd.sampling import get_black_box_solver
+    from oracle import ncsnpp_oracle as O
+    tb = C.param_tables()["tiny"]
+    w = C.synth_weights(tb["names"], tb["shapes"])
+    cfg = O.make_cfg(**C.TINY)
+    _, y, z = C.tiny_inputs()
+    got, nfe = get_black_box_solver(tiny.ode, tiny, y.cuda(), rtol=1e-4, atol=1e-4, z=z.cuda())()
+    ref, nfe_ref = get_black_box_solver(tiny.ode, lambda x, t, yy: O.vf_forward(w, cfg, x, t, yy), y, rtol=1e-4,
+                                        atol=1e-4, device="cpu", z=z)()
+    # adaptive step control turns 1e-6 differences of the field into O(tolerance) differences of the endpoint
+    print("black-box RK45: nfe", nfe, nfe_ref, "rel-L2", C.rel_l2(got.cpu(), ref))
+    assert abs(nfe - nfe_ref) <= 12
+    assert C.rel_l2(got.cpu(), ref) < 2e-3
+
+
 def test_rejects_cpu_and_bad_shapes(tiny):
     xt, y, _ = C.tiny_inputs()
     with pytest.raises(RuntimeError):

@@ -95,6 +95,46 @@ def test_conv2d_splitk(G, case):
     assert C.rel_l2(got, single) < 5e-6
 
 
+HALO_CASES = [
+    # B, H, W, C1, C2, Cout, bias2, res, scale, silu   (grid = B*H*W/128 * ceil(Cout/128) tiles must be >= 256)
+    (2, 128, 128, 128, 0, 128, True, True, 0.70710678, True),
+    (2, 256, 64, 256, 128, 128, True, False, 1.0, True),      # concat 384: GroupNorm group straddles the sources
+    (4, 64, 64, 128, 128, 256, False, True, 1.0, True),
+    (1, 256, 128, 128, 0, 4, False, True, 1.0, True),         # pyramid head, 32-wide N tile
+    (1, 128, 144, 32, 0, 160, False, False, 1.0, False),      # W = 9 tiles (not a power of two), no activation
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3x3_halo_fused_gn(G, case):
+    """LDS-halo 3x3 kernel with GroupNorm(+SiLU) applied while staging == conv(act(GN(cat[x1,x2])))."""
+    B, H, W, C1, C2, Cout, has_b2, has_res, scale, silu = case
+    Cc = C1 + C2
+    x1 = rnd(41, (B, C1, H, W)) * 1.5 + 0.3
+    x2 = rnd(42, (B, C2, H, W)) * 0.7 - 0.2 if C2 else None
+    g = 1.0 + rnd(43, (Cc,), 0.2)
+    be = rnd(44, (Cc,), 0.2)
+    w = rnd(45, (Cout, Cc, 3, 3), (1.0 / (Cc * 9)) ** 0.5)
+    bias = rnd(46, (Cout,), 0.1)
+    bias2 = rnd(47, (B, Cout + 4), 0.1) if has_b2 else None
+    res = rnd(48, (B, Cout, H, W)) if has_res else None
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    hn = F.group_norm(xin, min(Cc // 4, 32), g, be, eps=1e-6)
+    if silu:
+        hn = F.silu(hn)
+    ref = F.conv2d(hn, w, bias, padding=1)
+    if has_b2:
+        ref = ref + bias2[:, :Cout, None, None]
+    if has_res:
+        ref = ref + res
+    ref = ref * scale
+    got = G.conv3x3_gn(x1, g, be, w, bias, x2, bias2, res, scale, silu)
+    assert C.rel_l2(got, ref) < TOL
+    # the same kernel without the fused normalisation (plain 3x3 through the halo path)
+    plain = G.conv2d(hn, w, bias, None, bias2, res, scale)
+    assert C.rel_l2(plain, ref) < TOL
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 16, 8), (1, 128, 32, 32), (2, 16, 8, 8), (1, 512, 4, 4),
                                    (1, 256, 64, 64)])
 @pytest.mark.parametrize("silu", [True, False])
