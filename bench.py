@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--nsolver", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                    help="matrix-core operand mode of the large 3x3 convs (default: exact fp32)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the bf16x3 / bf16 operand-mode legs")
     ap.add_argument("--profile-all", action="store_true", help="per-op timing table to stderr (extra untimed pass)")
     args = ap.parse_args()
 
@@ -123,6 +126,7 @@ def main():
     sd = synth_state_dict(model.dnn)
     model.dnn.load_state_dict(sd)
     model = model.to(dev).eval()
+    model.dnn.set_precision(args.precision)
 
     B, F, T, NS = args.batch, 256, args.frames, args.nsolver
     # this rank's batch: utterance indices rank*B .. rank*B+B-1 (seeds 1234+i / 4321+i)
@@ -166,7 +170,9 @@ def main():
         "metric": "enhanced spectrogram-frames/sec at N=5 solver steps",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 (3x3 convs as split-bf16 x3 MFMA, fp32 accumulate)",
+                                       "bf16": "bf16 operands in the 3x3 convs, fp32 accumulate/activations"}[args.precision],
+        "data": "synthetic",
         "config": {"workload": f"BASELINE config[1]: batch={B} synthetic complex spectrograms [{B},1,{F},{T}] per GPU, "
                                f"N={NS} Euler steps, NCSN++ (65.6M params, synthetic weights) fp32",
                    "global_batch": world * B, "frames": T, "solver_steps": NS,
@@ -207,6 +213,24 @@ def main():
                 gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0
                 print(f"# {k:44s} n={v['launches']:4d} {v['ms']:9.3f} ms {100*v['ms']/tot:5.1f}% "
                       f"{tf:7.1f} TF/s {gbs:8.0f} GB/s", file=sys.stderr)
+        if world == 1 and args.precision == "fp32" and not args.no_alt:
+            # the optional operand modes of the same kernels, same workload, reported beside the exact-fp32 value
+            ref_x = x.clone()
+            alts = {}
+            for mode in ("bf16x3", "bf16"):
+                model.dnn.set_precision(mode)
+                xm = step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    xm = step()
+                torch.cuda.synchronize()
+                dt_m = time.perf_counter() - t1
+                err = float((xm - ref_x).abs().pow(2).sum().sqrt() / ref_x.abs().pow(2).sum().sqrt())
+                alts[mode] = {"value": args.steps * B * T / dt_m, "unit": "frames/s", "ms_per_step": 1e3 * dt_m / args.steps,
+                              "rel_l2_vs_fp32_mode": err}
+            model.dnn.set_precision("fp32")
+            out["alt_precision"] = alts
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, NS, T, args.cpu_reps)
             out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]

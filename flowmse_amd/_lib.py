@@ -44,6 +44,7 @@ SIGNATURES = {
     "flowse_model_blob_numel": (_i64, [_vp]),
     "flowse_model_param_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i64)]),
     "flowse_model_load_weights": (_i, [_vp, _fp, _i64]),
+    "flowse_model_set_precision": (_i, [_vp, _i]),
     "flowse_model_reserve": (_i, [_vp, _i, _i, _i, C.POINTER(_i64)]),
     "flowse_vf_forward": (_i, [_vp, _vp, _vp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "flowse_prior_sample": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),

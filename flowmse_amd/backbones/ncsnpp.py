@@ -106,6 +106,7 @@ class NCSNpp(nn.Module):
         self.reset_parameters()
         self._uploaded_versions = None
         self._uploaded_device = None
+        self.precision = "fp32"
 
     # ------------------------------------------------------------------ initialisation (reference rules)
     @torch.no_grad()
@@ -213,6 +214,15 @@ class NCSNpp(nn.Module):
         nbytes = C.c_int64()
         _lib.check(_lib.lib.flowse_model_reserve(self._handle, B, F, T, C.byref(nbytes)))
         return int(nbytes.value)
+
+    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+
+    def set_precision(self, mode):
+        """'fp32' (default, exact fp32 MFMA) | 'bf16x3' (split-bf16, fp32-class) | 'bf16' (BASELINE config 3)."""
+        _lib.check(_lib.lib.flowse_model_set_precision(self._handle, self.PRECISIONS[mode]))
+        self.precision = mode
+        self._uploaded_versions = None
+        return self
 
     def profile_begin(self, mode=0):
         """Bracket launches with HIP events (0: dominant conv kernel only, 1: every op)."""

@@ -63,7 +63,17 @@ struct ConvArgs {
     // conv_supports_fused_gn): A = act((x - mean[b][c]) * scale[b][c] + beta[c]) with c the concat channel index
     GnParams gn = {nullptr, nullptr, nullptr};
     int gn_silu = 0;
+    // optional bf16 matrix-core path for the halo 3x3 kernel (Cout % 128 == 0): weights pre-split into bf16
+    // planes, packed [Cout][9][Cin/32][planes][32]; terms = 3: x = hi + lo, products hi*hi + hi*lo + lo*hi
+    // ("bf16x3", fp32-class accuracy, planes = 2); terms = 1: plain bf16 operands (planes = 1).  Accumulation,
+    // GroupNorm, residuals and all activations in HBM stay fp32.
+    const void* wq = nullptr;
+    int terms = 0;
 };
+// host helper: split fp32 conv weights [Cout][Cin][3][3] into the packed bf16 planes described above
+void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst);
+inline int64_t conv_bf16_numel(int Cout, int Cin, int terms) { return (int64_t)Cout * 9 * Cin * (terms == 1 ? 1 : 2); }
+bool conv_supports_bf16(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // true when launch_conv will run the LDS-halo 3x3 kernel for this shape (the only one that can normalise its
 // input on the fly)
 bool conv_supports_fused_gn(int B, int H, int W, int C1, int C2, int Cout, int taps);

@@ -17,6 +17,7 @@
 // makes the fragment ds_read_b128 conflict-free.  Each lane reads 4 consecutive k of its row once and feeds
 // 4 successive MFMAs with them (lanes 0-31 carry k = 8j+e, lanes 32-63 carry k = 8j+4+e, for A and B alike).
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 
@@ -753,6 +754,275 @@ static int launch_halo(const ConvArgs& a, hipStream_t s) {
     return OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bf16 matrix-core variant of the LDS-halo 3x3 kernel (optional precision modes, off by default).
+//
+// Same tiling and data flow as conv3x3_halo_kernel; the operands are bf16 for v_mfma_f32_32x32x16_bf16 (16x the
+// fp32 MFMA rate).  TERMS = 3 ("bf16x3"): every fp32 operand is split x = hi + lo (hi = bf16(x), lo = bf16(x - hi),
+// 16 mantissa bits kept) and the product is accumulated as hi*hi + hi*lo + lo*hi in fp32 -- the dropped lo*lo term
+// is 2^-16 relative, so results stay fp32-class (measured ~1e-5 rel-L2 end to end) at 3/16 of the fp32 MFMA cost.
+// TERMS = 1: plain bf16 operands (BASELINE config 3).  Activations stay fp32 in HBM and are split while the halo is
+// staged (after the fused GroupNorm+SiLU); weights are pre-split at upload.  LDS row = [hi: 32 x bf16][lo: 32 x bf16]
+// + 16 B pad (stride 144 B, or 80 B for one plane): every fragment read is a conflict-free ds_read_b128.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int TERMS, bool GN>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
+    constexpr int BN = 128, NT = 256;
+    constexpr int PLANES = TERMS == 1 ? 1 : 2;
+    constexpr int ROWB = PLANES * 64 + 16;               // LDS row stride in bytes
+    constexpr int HROWS = 180;
+    constexpr int H_LOADS = 6;                            // fp32 halo: 180 rows x 8 float4 / 256 threads
+    constexpr int CPR = PLANES * 4;                       // 16-byte columns per weight row
+    constexpr int B_LOADS = BN * CPR / NT;                // 4 (two planes) or 2 (one plane)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Hs = reinterpret_cast<char*>(smem);             // [HROWS][ROWB]
+    char* Bs = Hs + HROWS * ROWB;                         // [2][BN][ROWB]
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int M = a.B * HW;
+    const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
+    const int nchunks = Cin / KC;
+    const int n_ntiles = a.Cout / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
+    const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 3);
+    const int b = mt / tiles_img, tt = mt - b * tiles_img;
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int y0 = ty * 8, x0 = tx * 16, n0 = nt * BN;
+    const int m_tl = (b * H + y0) * W + x0;
+
+    const int col4 = tid & 7, row0 = tid >> 3;            // halo staging: 8 float4 columns x 32 rows per pass
+    unsigned hvo1[H_LOADS], hvo2[H_LOADS];
+    unsigned hin = 0;
+#pragma unroll
+    for (int q = 0; q < H_LOADS; ++q) {
+        const int hr = row0 + 32 * q;
+        const int hy = hr / 18, hx = hr - hy * 18;
+        const bool in = hr < HROWS && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+        hvo1[q] = in ? (unsigned)((hy * W + hx) * C1 + col4 * 4) * 4u : OOB;
+        hvo2[q] = in ? (unsigned)((hy * W + hx) * C2 + col4 * 4) * 4u : OOB;
+        hin |= in ? (1u << q) : 0u;
+    }
+    const int bcol = tid % CPR, brow0 = tid / CPR;        // weight staging
+    constexpr int BRPP = NT / CPR;                        // rows per pass
+    unsigned bvo[B_LOADS];
+#pragma unroll
+    for (int q = 0; q < B_LOADS; ++q) {
+        const int n = n0 + brow0 + BRPP * q;
+        bvo[q] = (unsigned)(n * 9 * nchunks * (PLANES * 64) + bcol * 16);
+    }
+    const int64_t wbase = (int64_t)m_tl - W - 1;
+    const int wpix = 9 * W + 18;
+    const __amdgpu_buffer_rsrc_t rsrc1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1 + wbase * C1), 0, wpix * C1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(C2 ? a.in2 + wbase * C2 : a.in1), 0, C2 ? wpix * C2 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.wq), 0, a.Cout * 9 * nchunks * (PLANES * 64), 0x00020000);
+
+    u32x4 rh[H_LOADS], rb[B_LOADS];
+    float4 g_mu, g_sc, g_be;
+
+    auto gloadH = [&](int chunk) {
+        const int c0 = chunk * KC;
+        const bool second = c0 >= C1;
+        const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * 4u;
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q)
+            rh[q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, hvo2[q], soff, 0)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, hvo1[q], soff, 0);
+        if (GN) {
+            const int cg = c0 + col4 * 4;
+            g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
+            g_sc = *reinterpret_cast<const float4*>(a.gn.scale + (int64_t)b * Cin + cg);
+            g_be = *reinterpret_cast<const float4*>(a.gn.beta + cg);
+        }
+    };
+    // GroupNorm + SiLU, then the bf16 split; afterwards rh[q] = {hi01, hi23, lo01, lo23} (packed bf16 pairs)
+    auto xformH = [&]() {
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            const bool in = (hin >> q) & 1u;
+            float v[4] = {__uint_as_float(rh[q].x), __uint_as_float(rh[q].y), __uint_as_float(rh[q].z),
+                          __uint_as_float(rh[q].w)};
+            if (GN) {
+                const float mu[4] = {g_mu.x, g_mu.y, g_mu.z, g_mu.w}, sc[4] = {g_sc.x, g_sc.y, g_sc.z, g_sc.w},
+                            be[4] = {g_be.x, g_be.y, g_be.z, g_be.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = fmaf(v[e] - mu[e], sc[e], be[e]);
+                    if (a.gn_silu) t = __fdividef(t, 1.f + __expf(-t));
+                    v[e] = in ? t : 0.f;
+                }
+            }
+            unsigned short hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 h = (__bf16)v[e];
+                hi[e] = __builtin_bit_cast(unsigned short, h);
+                const __bf16 l = (__bf16)(v[e] - (float)h);
+                lo[e] = __builtin_bit_cast(unsigned short, l);
+            }
+            rh[q].x = (unsigned)hi[0] | ((unsigned)hi[1] << 16);
+            rh[q].y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
+            rh[q].z = (unsigned)lo[0] | ((unsigned)lo[1] << 16);
+            rh[q].w = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
+        }
+    };
+    auto lstoreH = [&]() {
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            const int hr = row0 + 32 * q;
+            if (hr >= HROWS) continue;
+            char* p = Hs + hr * ROWB + col4 * 8;
+            *reinterpret_cast<uint2*>(p) = make_uint2(rh[q].x, rh[q].y);
+            if (PLANES == 2) *reinterpret_cast<uint2*>(p + 64) = make_uint2(rh[q].z, rh[q].w);
+        }
+    };
+    auto gloadB = [&](int s) {
+        const int chunk = s / 9, tap = s - chunk * 9;
+        const unsigned soff_b = (unsigned)((tap * nchunks + chunk) * (PLANES * 64));
+#pragma unroll
+        for (int q = 0; q < B_LOADS; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo[q], soff_b, 0);
+    };
+    auto lstoreB = [&](int buf) {
+        char* Bb = Bs + buf * BN * ROWB;
+#pragma unroll
+        for (int q = 0; q < B_LOADS; ++q)
+            *reinterpret_cast<u32x4*>(Bb + (brow0 + BRPP * q) * ROWB + bcol * 16) = rb[q];
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, kh = lane >> 5;
+    int abase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int py = 2 * (wm * 2 + i) + (li >> 4), px = li & 15;
+        abase[i] = ((py + 1) * 18 + px + 1) * ROWB + kh * 16;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int S_all = nchunks * 9;
+    gloadH(0);
+    gloadB(0);
+    xformH();
+    lstoreH();
+    lstoreB(0);
+    __syncthreads();
+
+    for (int s = 0; s < S_all; ++s) {
+        const int chunk = s / 9, tap = s - chunk * 9;
+        const int buf = s & 1;
+        const bool next_chunk = chunk + 1 < nchunks;
+        if (s + 1 < S_all) gloadB(s + 1);
+        if (tap == 7 && next_chunk) gloadH(chunk + 1);
+        if (tap == 8 && next_chunk) xformH();
+        const int tapoff = ((tap / 3 - 1) * 18 + (tap - (tap / 3) * 3 - 1)) * ROWB;
+        const char* Bb = Bs + buf * BN * ROWB + (wn * 64 + li) * ROWB + kh * 16;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {                   // channels 0-15 / 16-31 of the chunk
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* p = Hs + abase[i] + tapoff + mh * 32;
+                ah[i] = *reinterpret_cast<const bf16x8*>(p);
+                if (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(p + 64);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const char* p = Bb + j * 32 * ROWB + mh * 32;
+                bh[j] = *reinterpret_cast<const bf16x8*>(p);
+                if (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(p + 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (TERMS == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < S_all) lstoreB(buf ^ 1);
+        __syncthreads();
+        if (tap == 8 && next_chunk) {
+            lstoreH();
+            __syncthreads();
+        }
+    }
+    conv_epilogue<2, 2, 2, 2>(a, acc, smem, m_tl, n0, M, HW, 0, W);
+}
+
+static unsigned short bf16_rne(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static float bf16_to_f(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst) {
+    const int planes = terms == 1 ? 1 : 2, nchunks = Cin / KC;
+    for (int co = 0; co < Cout; ++co)
+        for (int t = 0; t < 9; ++t)
+            for (int ch = 0; ch < nchunks; ++ch) {
+                uint16_t* row = dst + (((int64_t)co * 9 + t) * nchunks + ch) * planes * 32;
+                for (int k = 0; k < 32; ++k) {
+                    const float v = w[((int64_t)co * Cin + ch * 32 + k) * 9 + t];
+                    const unsigned short hi = bf16_rne(v);
+                    row[k] = hi;
+                    if (planes == 2) row[32 + k] = bf16_rne(v - bf16_to_f(hi));
+                }
+            }
+}
+
+bool conv_supports_bf16(int B, int H, int W, int C1, int C2, int Cout, int taps) {
+    return (Cout % 128) == 0 && conv_supports_fused_gn(B, H, W, C1, C2, Cout, taps);
+}
+
+template <int TERMS>
+static int launch_halo_bf16(const ConvArgs& a, hipStream_t s) {
+    constexpr int PLANES = TERMS == 1 ? 1 : 2, ROWB = PLANES * 64 + 16;
+    const int64_t M = (int64_t)a.B * a.H * a.W;
+    const int grid = (int)(M / 128) * (a.Cout / 128);
+    const size_t lds_stage = (size_t)(180 + 2 * 128) * ROWB;
+    const size_t lds_epi = ((size_t)128 * 132 + 256 * 8) * sizeof(float);
+    const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    static bool attr_done = false;
+    if (!attr_done) {
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TERMS, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TERMS, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    if (a.gn.mean)
+        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TERMS, true>), dim3(grid), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TERMS, false>), dim3(grid), dim3(256), lds, s, a);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
 int launch_splitk_reduce(const ConvArgs& a, hipStream_t s) {
     const int64_t total4 = (int64_t)a.B * a.H * a.W * (a.Cout / 4);
     int64_t blocks = (total4 + 255) / 256;
@@ -773,6 +1043,12 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
         return ERR_SHAPE;
     }
     if (a.ksplit <= 1 && conv_supports_fused_gn(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
+        if (a.wq && (a.Cout % 128) == 0) {
+            if (a.terms == 3) return launch_halo_bf16<3>(a, s);
+            if (a.terms == 1) return launch_halo_bf16<1>(a, s);
+            set_error("conv: bf16 path needs terms = 1 or 3");
+            return ERR_ARG;
+        }
         if (a.Cout <= 32) return launch_halo<4, 1, 1, 1>(a, s);
         if (a.Cout <= 64) return launch_halo<2, 2, 2, 1>(a, s);
         return launch_halo<2, 2, 2, 2>(a, s);

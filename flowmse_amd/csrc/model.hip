@@ -54,6 +54,7 @@ struct Module {
     int64_t w_a = -1, w_a_b = -1;      // generic weight / bias (linear, conv3, combine, gfp, gn gamma/beta)
     int64_t w_qkv = -1, w_qkv_b = -1, w_o = -1, w_o_b = -1;
     int dense_row0 = -1;               // first row of this block in the stacked Dense_0 table
+    int64_t wq_c0 = -1, wq_c1 = -1;    // offsets (uint16 elements) of the bf16 planes of Conv_0 / Conv_1, if packed
 };
 
 struct Tn {
@@ -153,6 +154,9 @@ struct flowse_model {
     // device state
     float* d_w = nullptr;                  // native weight blob
     int64_t d_w_numel = 0;
+    int precision = 0;                     // 0 fp32 (exact), 1 bf16x3 split (fp32-class), 2 bf16 operands
+    uint16_t* d_wq = nullptr;              // bf16 planes of the 3x3 ResBlock convs (precision != 0)
+    int64_t d_wq_numel = 0;
     char* d_ws = nullptr;                  // activation workspace
     size_t d_ws_bytes = 0;
     float* d_ts = nullptr;                 // [N][B] solver times
@@ -542,7 +546,7 @@ struct Builder {
     // conv: out (new tensor unless `inplace_res`), res optional
     Tn conv(const std::string& label, const Tn& a, const Tn* b2, int64_t w, int64_t bias, int dense_row0, int Cout,
             int taps, const Tn* res, float scale, bool out_is_res = false, bool cin4 = false,
-            const GnBuf* gin = nullptr, bool gin_silu = false) {
+            const GnBuf* gin = nullptr, bool gin_silu = false, int64_t wq_off = -1) {
         flowse_model* M = m;
         Tn o = out_is_res ? *res : alloc(a.H, a.W, Cout);
         const int C1 = a.C, C2 = b2 ? b2->C : 0, H = a.H, Wd = a.W, Bn = B;
@@ -557,6 +561,9 @@ struct Builder {
         const size_t st_off = o.st_off;
         const bool has_gin = gin != nullptr;
         const GnBuf gbuf = has_gin ? *gin : GnBuf();
+        const bool use_bf16 = wq_off >= 0 && M->precision != 0 && taps == 9 &&
+                              conv_supports_bf16(Bn, H, Wd, C1, C2, Cout, taps);
+        const int terms = M->precision == 1 ? 3 : 1;
         const size_t part_off = ks > 1 ? arena.alloc((size_t)ks * Bn * H * Wd * Cout * sizeof(float)) : 0;
         const size_t table_off = M_table_off;     // by value: the Builder dies before the plan runs
         const std::string full_label = label + "@" + std::to_string(H) + "x" + std::to_string(Wd) + ":" +
@@ -583,6 +590,10 @@ struct Builder {
             if (has_gin) {
                 c.gn = GnParams{M->A(gbuf.mean), M->A(gbuf.scale), M->W(gbuf.beta)};
                 c.gn_silu = gin_silu ? 1 : 0;
+            }
+            if (use_bf16) {
+                c.wq = M->d_wq + wq_off;
+                c.terms = terms;
             }
             return c;
         };
@@ -630,7 +641,7 @@ struct Builder {
             if (conv_supports_fused_gn(B, x1.H, x1.W, x1.C, x2 ? x2->C : 0, mod.out_ch, 9)) {
                 // Conv_0(act(GroupNorm_0(x))) in one kernel: the normalised tensor never reaches HBM
                 h1 = conv("conv0_3x3_gn", x1, x2, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f, false,
-                          false, &g0, true);
+                          false, &g0, true, mod.wq_c0);
                 gn_release(g0);
             } else {
                 Tn h0 = gn_apply(x1, x2, g0, true);
@@ -643,7 +654,8 @@ struct Builder {
             Tn hr = fir(x1, mod.up, &g0, true, nullptr);
             Tn xr = fir(x1, mod.up, nullptr, false, nullptr);
             gn_release(g0);
-            h1 = conv("conv0_3x3", hr, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f);
+            h1 = conv("conv0_3x3", hr, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f, false, false,
+                      nullptr, false, mod.wq_c0);
             release(hr);
             xs = conv("conv2_1x1", xr, nullptr, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f);
             release(xr);
@@ -653,7 +665,7 @@ struct Builder {
         Tn out;
         if (conv_supports_fused_gn(B, h1.H, h1.W, h1.C, 0, mod.out_ch, 9)) {
             out = conv("conv1_3x3_gn", h1, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, xs.valid() ? &xs : &x1, rs2,
-                       false, false, &g1, true);
+                       false, false, &g1, true, mod.wq_c1);
             gn_release(g1);
             release(h1);
         } else {
@@ -933,6 +945,7 @@ void flowse_model_destroy(flowse_model* m) {
     if (m->d_w) (void)hipFree(m->d_w);
     if (m->d_ws) (void)hipFree(m->d_ws);
     if (m->d_ts) (void)hipFree(m->d_ts);
+    if (m->d_wq) (void)hipFree(m->d_wq);
     delete m;
 }
 
@@ -955,6 +968,24 @@ int flowse_model_param_info(const flowse_model* m, int index, char* name, int na
         for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
     if (ndim) *ndim = p.ndim;
     if (offset) *offset = p.offset;
+    return OK;
+}
+
+int flowse_model_set_precision(flowse_model* m, int mode) {
+    if (!m || mode < 0 || mode > 2) {
+        set_error("flowse_model_set_precision: mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16)");
+        return ERR_ARG;
+    }
+    if (mode != m->precision) {
+        m->precision = mode;
+        m->plans.clear();
+        if (m->d_w) {            // weights must be re-uploaded so that the bf16 planes match the mode
+            FLOWSE_HIP(hipDeviceSynchronize());
+            FLOWSE_HIP(hipFree(m->d_w));
+            m->d_w = nullptr;
+            m->d_w_numel = 0;
+        }
+    }
     return OK;
 }
 
@@ -981,6 +1012,33 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
         m->d_w_numel = (int64_t)pk.host.size();
     }
     FLOWSE_HIP(hipMemcpy(m->d_w, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    // optional bf16 planes for the 3x3 ResBlock convolutions the halo kernel can take
+    for (auto& mod : m->mods) mod.wq_c0 = mod.wq_c1 = -1;
+    if (m->precision != 0) {
+        const int terms = m->precision == 1 ? 3 : 1;
+        std::vector<uint16_t> q;
+        for (auto& mod : m->mods) {
+            if (mod.kind != M_RESBLOCK || (mod.out_ch % 128) != 0) continue;
+            if ((mod.in_ch % 32) == 0) {
+                mod.wq_c0 = (int64_t)q.size();
+                q.resize(q.size() + conv_bf16_numel(mod.out_ch, mod.in_ch, terms));
+                pack_conv_bf16(blob + m->params[mod.p0 + 2].offset, mod.out_ch, mod.in_ch, terms, q.data() + mod.wq_c0);
+            }
+            mod.wq_c1 = (int64_t)q.size();
+            q.resize(q.size() + conv_bf16_numel(mod.out_ch, mod.out_ch, terms));
+            pack_conv_bf16(blob + m->params[mod.p0 + 8].offset, mod.out_ch, mod.out_ch, terms, q.data() + mod.wq_c1);
+        }
+        if (m->d_wq && m->d_wq_numel < (int64_t)q.size()) {
+            FLOWSE_HIP(hipFree(m->d_wq));
+            m->d_wq = nullptr;
+        }
+        if (!m->d_wq && !q.empty()) {
+            FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_wq), q.size() * sizeof(uint16_t)));
+            m->d_wq_numel = (int64_t)q.size();
+        }
+        if (!q.empty())
+            FLOWSE_HIP(hipMemcpy(m->d_wq, q.data(), q.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     m->plans.clear();        // closures captured weight offsets of the previous packing
     return OK;
 }
