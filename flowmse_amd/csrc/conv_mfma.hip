@@ -666,33 +666,97 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     return OK;
 }
 
-// out = (sum_s partial[s] + bias + bias2 + res) * scale, float4 streams
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, int64_t total4) {
-    const int Q = a.Cout >> 2;
-    const int HW = a.H * a.W;
+// out = (sum_s partial[s] + bias + bias2 + res) * scale, float4 streams; grid (ceil(HW * Cout/4 / 256), B)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
+    const unsigned Q = a.Cout >> 2;
+    const unsigned HW = a.H * a.W;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= HW * Q) return;
+    const int b = blockIdx.y;
+    const int n = (idx % Q) * 4;
+    const int64_t i4 = ((int64_t)b * HW * Q + idx) * 4;            // float offset of this quad
     const int64_t slice = (int64_t)a.B * HW * a.Cout;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int64_t m = i / Q;
-        const int n = (int)(i - m * Q) * 4;
-        float4 v = *reinterpret_cast<const float4*>(a.partial + i * 4);
-        for (int s = 1; s < a.ksplit; ++s) {
-            const float4 t = *reinterpret_cast<const float4*>(a.partial + s * slice + i * 4);
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
-        if (a.bias) {
-            const float4 t = *reinterpret_cast<const float4*>(a.bias + n);
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
+    float4 v = *reinterpret_cast<const float4*>(a.partial + i4);
+#pragma unroll 8
+    for (int s = 1; s < a.ksplit; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(a.partial + s * slice + i4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (a.bias) {
+        const float4 t = *reinterpret_cast<const float4*>(a.bias + n);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (a.bias2) {
+        const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)b * a.bias2_stride + n);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (a.res) {
+        const float4 t = *reinterpret_cast<const float4*>(a.res + i4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
+    *reinterpret_cast<float4*>(a.out + i4) = v;
+}
+
+// Same reduction, organised like gn_stats (grid (HW / PB, B); a thread owns one channel quad and strides over the
+// block's PB pixels) so that it can also emit the GroupNorm partial sums of the tensor it writes:
+// stats[((b * nblk + blk) * Cout + c) * 2 + {0,1}].
+constexpr int SK_PB = 8;      // pixels per block (small: these tensors are tiny, parallelism matters)
+
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(ConvArgs a, int PB) {
+    __shared__ float red[256 * 8];
+    const int Q = a.Cout >> 2, PR = 256 / Q;
+    const int HW = a.H * a.W;
+    const int tid = threadIdx.x;
+    const int pr = tid / Q, cq = tid - pr * Q;
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int n = cq * 4;
+    const int64_t slice = (int64_t)a.B * HW * a.Cout;
+    float4 st_s = make_float4(0.f, 0.f, 0.f, 0.f), st_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pr < PR) {
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + n);
         if (a.bias2) {
-            const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (m / HW) * a.bias2_stride + n);
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)b * a.bias2_stride + n);
+            bq.x += t.x; bq.y += t.y; bq.z += t.z; bq.w += t.w;
         }
-        if (a.res) {
-            const float4 t = *reinterpret_cast<const float4*>(a.res + i * 4);
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        for (int p = blk * PB + pr; p < (blk + 1) * PB; p += PR) {
+            const int64_t i4 = ((int64_t)b * HW + p) * a.Cout + n;
+            float4 v = *reinterpret_cast<const float4*>(a.partial + i4);
+#pragma unroll 8
+            for (int s = 1; s < a.ksplit; ++s) {           // independent loads: keep many in flight
+                const float4 t = *reinterpret_cast<const float4*>(a.partial + s * slice + i4);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+            if (a.res) {
+                const float4 t = *reinterpret_cast<const float4*>(a.res + i4);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
+            *reinterpret_cast<float4*>(a.out + i4) = v;
+            st_s.x += v.x; st_s.y += v.y; st_s.z += v.z; st_s.w += v.w;
+            st_q.x = fmaf(v.x, v.x, st_q.x); st_q.y = fmaf(v.y, v.y, st_q.y);
+            st_q.z = fmaf(v.z, v.z, st_q.z); st_q.w = fmaf(v.w, v.w, st_q.w);
         }
-        v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
-        *reinterpret_cast<float4*>(a.out + i * 4) = v;
+    }
+    float* mine = red + tid * 8;
+    mine[0] = st_s.x; mine[1] = st_s.y; mine[2] = st_s.z; mine[3] = st_s.w;
+    mine[4] = st_q.x; mine[5] = st_q.y; mine[6] = st_q.z; mine[7] = st_q.w;
+    __syncthreads();
+    if (pr == 0) {
+        float acc8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc8[j] = mine[j];
+        for (int r = 1; r < PR; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc8[j] += red[(r * Q + cq) * 8 + j];
+        float* dst = a.stats + (((int64_t)b * a.stats_nblk + blk) * a.Cout + n) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dst[2 * j] = acc8[j];
+            dst[2 * j + 1] = acc8[4 + j];
+        }
     }
 }
 
@@ -700,8 +764,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, int64_t 
 // until ~512 blocks exist, keeping >= 4 K steps per slice.
 int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps) {
     const int HW = H * W;
-    if ((HW % 128) != 0 || (Cout & 3) || conv_ksplit(B, H, W, Cin, Cout, taps) != 1) return 0;
-    return HW / 128;
+    if (Cout & 3) return 0;
+    if (conv_ksplit(B, H, W, Cin, Cout, taps) != 1) {      // statistics come from the split-K reduction pass
+        const int PB = HW < SK_PB ? HW : SK_PB;
+        return ((HW % PB) == 0 && Cout / 4 <= 256) ? HW / PB : 0;
+    }
+    return (HW % 128) == 0 ? HW / 128 : 0;
 }
 
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
@@ -1024,10 +1092,19 @@ static int launch_halo_bf16(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_splitk_reduce(const ConvArgs& a, hipStream_t s) {
-    const int64_t total4 = (int64_t)a.B * a.H * a.W * (a.Cout / 4);
-    int64_t blocks = (total4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, a, total4);
+    const int HW = a.H * a.W;
+    if (a.stats) {
+        const int PB = HW < SK_PB ? HW : SK_PB;
+        if (a.stats_nblk != HW / PB || (HW % PB) != 0 || a.Cout / 4 > 256) {
+            set_error("splitk_reduce: inconsistent fused-stats geometry");
+            return ERR_ARG;
+        }
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(HW / PB, a.B), dim3(256), 0, s, a, PB);
+        FLOWSE_LAUNCH_CHECK();
+        return OK;
+    }
+    const unsigned per_sample = (unsigned)HW * (a.Cout / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((per_sample + 255) / 256, a.B), dim3(256), 0, s, a);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }

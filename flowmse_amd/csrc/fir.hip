@@ -47,89 +47,83 @@ __device__ __forceinline__ GnQuad gn_quad(const GnParams& gn, int silu, int b, i
     return g;
 }
 
-__global__ __launch_bounds__(256) void fir_down_kernel(const float* __restrict__ in, int B, int H, int W, int C,
-                                                       GnParams gn, int silu, float* __restrict__ out,
-                                                       int64_t total4) {
-    const int Q = C >> 2, OH = H >> 1, OW = W >> 1;
+// grid: (ceil(OW * C/4 / 256), OH, B); one thread = one output pixel x one channel quad (32-bit index math only)
+__global__ __launch_bounds__(256) void fir_down_kernel(const float* __restrict__ in, int H, int W, int C, GnParams gn,
+                                                       int silu, float* __restrict__ out) {
+    const unsigned Q = C >> 2, OW = W >> 1, OH = H >> 1;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= OW * Q) return;
+    const unsigned ox = idx / Q, cq = idx - ox * Q;
+    const int oy = blockIdx.y, b = blockIdx.z;
+    const int c = cq * 4;
     const float k1[4] = {1.f, 3.f, 3.f, 1.f};
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int cq = (int)(i % Q);
-        int64_t pix = i / Q;
-        const int ox = (int)(pix % OW);
-        pix /= OW;
-        const int oy = (int)(pix % OH);
-        const int b = (int)(pix / OH);
-        const int c = cq * 4;
-        const GnQuad g = gn_quad(gn, silu, b, C, c);
-        const float* base = in + (int64_t)b * H * W * C + c;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const GnQuad g = gn_quad(gn, silu, b, C, c);
+    const float* base = in + (int64_t)b * H * W * C + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int ty = 0; ty < 4; ++ty) {
-            const int y = 2 * oy - 1 + ty;
-            if ((unsigned)y >= (unsigned)H) continue;
-            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ty = 0; ty < 4; ++ty) {
+        const int y = 2 * oy - 1 + ty;
+        if ((unsigned)y >= (unsigned)H) continue;
+        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int tx = 0; tx < 4; ++tx) {
-                const int x = 2 * ox - 1 + tx;
-                if ((unsigned)x >= (unsigned)W) continue;
-                const float4 v = load_tx(base + ((int64_t)y * W + x) * C, g);
-                row.x = fmaf(k1[tx], v.x, row.x); row.y = fmaf(k1[tx], v.y, row.y);
-                row.z = fmaf(k1[tx], v.z, row.z); row.w = fmaf(k1[tx], v.w, row.w);
-            }
-            acc.x = fmaf(k1[ty], row.x, acc.x); acc.y = fmaf(k1[ty], row.y, acc.y);
-            acc.z = fmaf(k1[ty], row.z, acc.z); acc.w = fmaf(k1[ty], row.w, acc.w);
+        for (int tx = 0; tx < 4; ++tx) {
+            const int x = 2 * (int)ox - 1 + tx;
+            if ((unsigned)x >= (unsigned)W) continue;
+            const float4 v = load_tx(base + ((int64_t)y * W + x) * C, g);
+            row.x = fmaf(k1[tx], v.x, row.x); row.y = fmaf(k1[tx], v.y, row.y);
+            row.z = fmaf(k1[tx], v.z, row.z); row.w = fmaf(k1[tx], v.w, row.w);
         }
-        const float s = 1.f / 64.f;
-        *reinterpret_cast<float4*>(out + i * 4) = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
+        acc.x = fmaf(k1[ty], row.x, acc.x); acc.y = fmaf(k1[ty], row.y, acc.y);
+        acc.z = fmaf(k1[ty], row.z, acc.z); acc.w = fmaf(k1[ty], row.w, acc.w);
     }
+    const float s = 1.f / 64.f;
+    float* o = out + (((int64_t)b * OH + oy) * OW + ox) * C + c;
+    *reinterpret_cast<float4*>(o) = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
 }
 
-__global__ __launch_bounds__(256) void fir_up_kernel(const float* __restrict__ in, int B, int H, int W, int C,
-                                                     GnParams gn, int silu, const float* __restrict__ add,
-                                                     float* __restrict__ out, int64_t total4) {
-    const int Q = C >> 2, OH = H * 2, OW = W * 2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int cq = (int)(i % Q);
-        int64_t pix = i / Q;
-        const int ox = (int)(pix % OW);
-        pix /= OW;
-        const int oy = (int)(pix % OH);
-        const int b = (int)(pix / OH);
-        const int c = cq * 4;
-        const GnQuad g = gn_quad(gn, silu, b, C, c);
-        const float* base = in + (int64_t)b * H * W * C + c;
-        // per axis: two taps (position, weight); even: (a-1, 1), (a, 3); odd: (a, 3), (a+1, 1)
-        const int ay = oy >> 1, ax = ox >> 1;
-        const int y0 = (oy & 1) ? ay : ay - 1, x0 = (ox & 1) ? ax : ax - 1;
-        const float wy0 = (oy & 1) ? 3.f : 1.f, wy1 = (oy & 1) ? 1.f : 3.f;
-        const float wx0 = (ox & 1) ? 3.f : 1.f, wx1 = (ox & 1) ? 1.f : 3.f;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+// grid: (ceil(2W * C/4 / 256), 2H, B)
+__global__ __launch_bounds__(256) void fir_up_kernel(const float* __restrict__ in, int H, int W, int C, GnParams gn,
+                                                     int silu, const float* __restrict__ add, float* __restrict__ out) {
+    const unsigned Q = C >> 2, OW = W * 2, OH = H * 2;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= OW * Q) return;
+    const unsigned ox = idx / Q, cq = idx - ox * Q;
+    const int oy = blockIdx.y, b = blockIdx.z;
+    const int c = cq * 4;
+    const GnQuad g = gn_quad(gn, silu, b, C, c);
+    const float* base = in + (int64_t)b * H * W * C + c;
+    // per axis: two taps (position, weight); even: (a-1, 1), (a, 3); odd: (a, 3), (a+1, 1)
+    const int ay = oy >> 1, ax = ox >> 1;
+    const int y0 = (oy & 1) ? ay : ay - 1, x0 = (ox & 1) ? ax : ax - 1;
+    const float wy0 = (oy & 1) ? 3.f : 1.f, wy1 = (oy & 1) ? 1.f : 3.f;
+    const float wx0 = (ox & 1) ? 3.f : 1.f, wx1 = (ox & 1) ? 1.f : 3.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int ty = 0; ty < 2; ++ty) {
-            const int y = y0 + ty;
-            if ((unsigned)y >= (unsigned)H) continue;
-            const float wy = ty ? wy1 : wy0;
-            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ty = 0; ty < 2; ++ty) {
+        const int y = y0 + ty;
+        if ((unsigned)y >= (unsigned)H) continue;
+        const float wy = ty ? wy1 : wy0;
+        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int tx = 0; tx < 2; ++tx) {
-                const int x = x0 + tx;
-                if ((unsigned)x >= (unsigned)W) continue;
-                const float wx = tx ? wx1 : wx0;
-                const float4 v = load_tx(base + ((int64_t)y * W + x) * C, g);
-                row.x = fmaf(wx, v.x, row.x); row.y = fmaf(wx, v.y, row.y);
-                row.z = fmaf(wx, v.z, row.z); row.w = fmaf(wx, v.w, row.w);
-            }
-            acc.x = fmaf(wy, row.x, acc.x); acc.y = fmaf(wy, row.y, acc.y);
-            acc.z = fmaf(wy, row.z, acc.z); acc.w = fmaf(wy, row.w, acc.w);
+        for (int tx = 0; tx < 2; ++tx) {
+            const int x = x0 + tx;
+            if ((unsigned)x >= (unsigned)W) continue;
+            const float wx = tx ? wx1 : wx0;
+            const float4 v = load_tx(base + ((int64_t)y * W + x) * C, g);
+            row.x = fmaf(wx, v.x, row.x); row.y = fmaf(wx, v.y, row.y);
+            row.z = fmaf(wx, v.z, row.z); row.w = fmaf(wx, v.w, row.w);
         }
-        const float s = 1.f / 16.f;
-        float4 o = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
-        if (add) {
-            const float4 r = *reinterpret_cast<const float4*>(add + i * 4);
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
-        *reinterpret_cast<float4*>(out + i * 4) = o;
+        acc.x = fmaf(wy, row.x, acc.x); acc.y = fmaf(wy, row.y, acc.y);
+        acc.z = fmaf(wy, row.z, acc.z); acc.w = fmaf(wy, row.w, acc.w);
     }
+    const float s = 1.f / 16.f;
+    float4 o = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
+    const int64_t off = (((int64_t)b * OH + oy) * OW + ox) * C + c;
+    if (add) {
+        const float4 r = *reinterpret_cast<const float4*>(add + off);
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    *reinterpret_cast<float4*>(out + off) = o;
 }
 
 static int grid_for(int64_t total) {
@@ -140,25 +134,26 @@ static int grid_for(int64_t total) {
 }
 
 int launch_fir_down(const float* in, int B, int H, int W, int C, GnParams gn, int silu, float* out, hipStream_t s) {
-    if ((C & 3) || (H & 1) || (W & 1)) {
-        set_error("fir_down: unsupported shape H=%d W=%d C=%d", H, W, C);
+    if ((C & 3) || (H & 1) || (W & 1) || H / 2 > 65535 || B > 65535) {
+        set_error("fir_down: unsupported shape B=%d H=%d W=%d C=%d", B, H, W, C);
         return ERR_SHAPE;
     }
-    const int64_t total4 = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(fir_down_kernel, dim3(grid_for(total4)), dim3(256), 0, s, in, B, H, W, C, gn, silu, out, total4);
+    const unsigned per_row = (unsigned)(W / 2) * (C / 4);
+    hipLaunchKernelGGL(fir_down_kernel, dim3((per_row + 255) / 256, H / 2, B), dim3(256), 0, s, in, H, W, C, gn, silu,
+                       out);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
 
 int launch_fir_up(const float* in, int B, int H, int W, int C, GnParams gn, int silu, const float* add, float* out,
                   hipStream_t s) {
-    if (C & 3) {
-        set_error("fir_up: unsupported C=%d", C);
+    if ((C & 3) || H * 2 > 65535 || B > 65535) {
+        set_error("fir_up: unsupported shape B=%d H=%d C=%d", B, H, C);
         return ERR_SHAPE;
     }
-    const int64_t total4 = (int64_t)B * (H * 2) * (W * 2) * (C / 4);
-    hipLaunchKernelGGL(fir_up_kernel, dim3(grid_for(total4)), dim3(256), 0, s, in, B, H, W, C, gn, silu, add, out,
-                       total4);
+    const unsigned per_row = (unsigned)(W * 2) * (C / 4);
+    hipLaunchKernelGGL(fir_up_kernel, dim3((per_row + 255) / 256, H * 2, B), dim3(256), 0, s, in, H, W, C, gn, silu, add,
+                       out);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }

@@ -111,30 +111,29 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); }
 
-// grid-stride over float4 elements of the output [B][HW][C]
+// grid (ceil(HW * C/4 / 256), B): one float4 per thread, 32-bit index math only
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ in1, int C1,
-                                                       const float* __restrict__ in2, int C2, int HW, int64_t total4,
-                                                       GnParams gn, int silu, float* __restrict__ out) {
-    const int C = C1 + C2, Q = C >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int64_t pix = i / Q;
-        const int cq = (int)(i - pix * Q);
-        const int c = cq * 4;
-        const int b = (int)(pix / HW);
-        float4 v;
-        if (c < C1) v = *reinterpret_cast<const float4*>(in1 + pix * C1 + c);
-        else v = *reinterpret_cast<const float4*>(in2 + pix * C2 + (c - C1));
-        const float4 mu = *reinterpret_cast<const float4*>(gn.mean + (int64_t)b * C + c);
-        const float4 sc = *reinterpret_cast<const float4*>(gn.scale + (int64_t)b * C + c);
-        const float4 be = *reinterpret_cast<const float4*>(gn.beta + c);
-        float4 o;
-        o.x = fmaf(v.x - mu.x, sc.x, be.x);
-        o.y = fmaf(v.y - mu.y, sc.y, be.y);
-        o.z = fmaf(v.z - mu.z, sc.z, be.z);
-        o.w = fmaf(v.w - mu.w, sc.w, be.w);
-        if (silu) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
-        *reinterpret_cast<float4*>(out + i * 4) = o;
-    }
+                                                       const float* __restrict__ in2, int C2, int HW, GnParams gn,
+                                                       int silu, float* __restrict__ out) {
+    const unsigned C = C1 + C2, Q = C >> 2;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)HW * Q) return;
+    const unsigned pix_s = idx / Q, cq = idx - pix_s * Q;
+    const int c = cq * 4, b = blockIdx.y;
+    const int64_t pix = (int64_t)b * HW + pix_s;
+    float4 v;
+    if (c < C1) v = *reinterpret_cast<const float4*>(in1 + pix * C1 + c);
+    else v = *reinterpret_cast<const float4*>(in2 + pix * C2 + (c - C1));
+    const float4 mu = *reinterpret_cast<const float4*>(gn.mean + (int64_t)b * C + c);
+    const float4 sc = *reinterpret_cast<const float4*>(gn.scale + (int64_t)b * C + c);
+    const float4 be = *reinterpret_cast<const float4*>(gn.beta + c);
+    float4 o;
+    o.x = fmaf(v.x - mu.x, sc.x, be.x);
+    o.y = fmaf(v.y - mu.y, sc.y, be.y);
+    o.z = fmaf(v.z - mu.z, sc.z, be.z);
+    o.w = fmaf(v.w - mu.w, sc.w, be.w);
+    if (silu) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
+    *reinterpret_cast<float4*>(out + pix * C + c) = o;
 }
 
 int launch_gn_stats(const float* in1, int C1, const float* in2, int C2, int B, int HW, float* partial, int nblk,
@@ -164,11 +163,13 @@ int launch_gn_finalize(const float* partial1, int nblk1, int C1, const float* pa
 
 int launch_gn_apply(const float* in1, int C1, const float* in2, int C2, int B, int HW, GnParams gn, int silu,
                     float* out, hipStream_t s) {
-    const int64_t total4 = (int64_t)B * HW * ((C1 + C2) / 4);
-    int64_t blocks = (total4 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, s, in1, C1, in2, C2, HW, total4, gn, silu,
-                       out);
+    const int64_t per_sample = (int64_t)HW * ((C1 + C2) / 4);
+    if (per_sample >= (1LL << 32) || B > 65535) {
+        set_error("gn_apply: tensor too large");
+        return ERR_SHAPE;
+    }
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((per_sample + 255) / 256), B), dim3(256), 0, s, in1, C1, in2, C2,
+                       HW, gn, silu, out);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
