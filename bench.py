@@ -113,10 +113,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if os.environ.get("FLOWSE_BENCH_SHARE_GPU"):                 # test hook: every rank on device 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("FLOWSE_BENCH_BACKEND", "nccl")     # "gloo": CI on a box where ranks share one GPU
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from flowmse_amd.model import VFModel
     from flowmse_amd.sampling import get_white_box_solver
@@ -153,13 +159,16 @@ def main():
     for _ in range(args.steps):
         x = step()
     if world > 1:                                  # the path's only exchange: final gather of enhanced specs
-        gathered = [torch.empty_like(torch.view_as_real(x)) for _ in range(world)] if rank == 0 else None
-        dist.gather(torch.view_as_real(x).contiguous(), gathered, dst=0)
+        payload = torch.view_as_real(x).contiguous()
+        if backend != "nccl":
+            payload = payload.cpu()
+        gathered = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+        dist.gather(payload, gathered, dst=0)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = model.dnn.profile_end()
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(torch.view_as_real(x)).all(), "non-finite output"
