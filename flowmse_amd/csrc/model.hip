@@ -946,6 +946,7 @@ void flowse_model_destroy(flowse_model* m) {
     if (m->d_ws) (void)hipFree(m->d_ws);
     if (m->d_ts) (void)hipFree(m->d_ts);
     if (m->d_wq) (void)hipFree(m->d_wq);
+    for (hipEvent_t e : m->prof_pool) (void)hipEventDestroy(e);
     delete m;
 }
 

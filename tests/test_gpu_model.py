@@ -245,6 +245,30 @@ def test_bf16x3_sampler_within_bar(full):
     assert err < 1e-3
 
 
+@pytest.mark.timeout(600)
+def test_end_to_end_utterance_vs_oracle(full, tmp_path):
+    """evaluate.py flow on one synthetic 2 s utterance (251 -> 256 frames), N=2: HIP sampler vs the oracle field
+    driven through the same host code; then the CLI counterpart on synthetic pairs."""
+    from flowmse_amd.evaluate import enhance_waveform, main
+    from oracle import ncsnpp_oracle as O
+    tb = C.param_tables()["full"]
+    w = C.synth_weights(tb["names"], tb["shapes"])
+    sig = torch.from_numpy(synth.normal(3, 9, (1, 32000), 0.1))
+    Tpad = 256
+    z = C.c64(synth.synth_noise(2, 1, 256, Tpad))
+    ref = enhance_waveform(full, sig, N=2, z=z, VF_fn=lambda x, t, y: O.vf_forward(w, O.make_cfg(), x, t, y),
+                           device="cpu")
+    got = enhance_waveform(full, sig.cuda(), N=2, z=z.cuda())
+    err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    print("end-to-end waveform rel-L2 vs oracle pipeline", err)
+    assert got.shape == (32000,) and err < 1e-3
+    out = str(tmp_path / "enh")
+    assert main(["--folder_destination", out, "--synthetic", "2", "--N", "2"]) == 0
+    import os
+    assert sorted(os.listdir(out + "/files")) == ["synthetic_00.wav", "synthetic_01.wav"]
+    assert os.path.exists(out + "/_results.csv") and os.path.exists(out + "/_settings.txt")
+
+
 def test_rejects_cpu_and_bad_shapes(tiny):
     xt, y, _ = C.tiny_inputs()
     with pytest.raises(RuntimeError):
