@@ -14,6 +14,20 @@ from flowmse_amd.util.registry import Registry
 ODEsolverRegistry = Registry("ODEsolver")
 
 
+def axpy(x, k, dt):
+    """x + dt * k.  On the GPU this is the library's ``flowse_axpy`` kernel (complex64 tensors on 'cuda'); for
+    anything else (the plugin loop accepts arbitrary callables / devices, like the reference) plain tensor math."""
+    if x.is_cuda and k.is_cuda and x.dtype == torch.complex64 and k.dtype == torch.complex64 and x.shape == k.shape:
+        from flowmse_amd import _lib
+        x, k = x.contiguous(), k.contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib.flowse_axpy(_lib.ptr(x), _lib.ptr(k), float(dt), _lib.ptr(out), x.numel(),
+                                            _lib.current_stream()))
+        return out
+    return x + k * dt
+
+
 class ODEsolver(abc.ABC):
     nfe_per_step = 1
 
@@ -32,7 +46,7 @@ class EulerODEsolver(ODEsolver):
     def update_fn(self, x, t, y, stepsize, *args):
         dt = -stepsize
         vectorfield = self.VF_fn(x, t, y)
-        return x + vectorfield * dt
+        return axpy(x, vectorfield, dt)
 
 
 @ODEsolverRegistry.register("heun")
@@ -44,8 +58,8 @@ class HeunODEsolver(ODEsolver):
         dt = -stepsize
         k1 = self.VF_fn(x, t, y)
         t2 = torch.clamp(t + dt, min=1e-4)          # the network divides by t
-        k2 = self.VF_fn(x + k1 * dt, t2, y)
-        return x + (k1 + k2) * (0.5 * dt)
+        k2 = self.VF_fn(axpy(x, k1, dt), t2, y)
+        return axpy(axpy(x, k1, 0.5 * dt), k2, 0.5 * dt)
 
 
 @ODEsolverRegistry.register("rk4")
@@ -58,7 +72,10 @@ class RK4ODEsolver(ODEsolver):
         th = torch.clamp(t + 0.5 * dt, min=1e-4)
         te = torch.clamp(t + dt, min=1e-4)
         k1 = self.VF_fn(x, t, y)
-        k2 = self.VF_fn(x + k1 * (0.5 * dt), th, y)
-        k3 = self.VF_fn(x + k2 * (0.5 * dt), th, y)
-        k4 = self.VF_fn(x + k3 * dt, te, y)
-        return x + (k1 + 2 * k2 + 2 * k3 + k4) * (dt / 6.0)
+        k2 = self.VF_fn(axpy(x, k1, 0.5 * dt), th, y)
+        k3 = self.VF_fn(axpy(x, k2, 0.5 * dt), th, y)
+        k4 = self.VF_fn(axpy(x, k3, dt), te, y)
+        out = axpy(x, k1, dt / 6.0)
+        out = axpy(out, k2, dt / 3.0)
+        out = axpy(out, k3, dt / 3.0)
+        return axpy(out, k4, dt / 6.0)

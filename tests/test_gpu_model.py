@@ -263,7 +263,7 @@ def test_end_to_end_utterance_vs_oracle(full, tmp_path):
     print("end-to-end waveform rel-L2 vs oracle pipeline", err)
     assert got.shape == (32000,) and err < 1e-3
     out = str(tmp_path / "enh")
-    assert main(["--folder_destination", out, "--synthetic", "2", "--N", "2"]) == 0
+    assert main(["--folder_destination", out, "--synthetic", "2", "--N", "2", "--batch", "2"]) == 0
     import os
     assert sorted(os.listdir(out + "/files")) == ["synthetic_00.wav", "synthetic_01.wav"]
     assert os.path.exists(out + "/_results.csv") and os.path.exists(out + "/_settings.txt")
