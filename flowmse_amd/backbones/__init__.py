@@ -1,4 +1,5 @@
-from .shared import BackboneRegistry
-from .ncsnpp import NCSNpp
+"""Backbone plugins of the HIP sampler: only ``"ncsnpp"`` (the released FlowSE configuration) is provided."""
+from .ncsnpp import NCSNpp  # noqa: F401  (registers itself)
+from .shared import BackboneRegistry  # noqa: F401
 
-__all__ = ["BackboneRegistry", "NCSNpp"]
+__all__ = ("BackboneRegistry", "NCSNpp")

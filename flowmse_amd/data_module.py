@@ -1,62 +1,69 @@
-"""Spectrogram transforms either side of the sampler (reference: flowmse/data_module.py:149-205).
+"""Spectrogram transforms on either side of the sampler.
 
-STFT n_fft 510 / hop 128 / periodic hann / center=True, and the magnitude compression
-``|z|^e exp(j angle z) * factor`` with its inverse.  These are the "next" rows of the hot-path scope table
-(SURVEY.md section 8(f)); they run as plain torch ops (plumbing) on whatever device the signal lives on.
-The dataset / dataloader side of SpecsDataModule is training infrastructure and out of scope.
+Mirror of the transform half of the reference's ``SpecsDataModule`` (flowmse/data_module.py:149-205): STFT with
+n_fft 510 (256 bins), hop 128, periodic Hann, centred frames, and the magnitude compression
+``c * |z|^e * exp(j arg z)`` (e = 0.5, c = 0.15) with its inverse.  These are the "next" rows of the hot-path scope
+(SURVEY.md section 8(f)); they run as torch ops (plumbing) on the device of the signal.  Dataset / dataloader code
+of the reference is training infrastructure and is not reproduced.
 """
 import torch
 
 
+def _window(kind, n_fft):
+    base = torch.hann_window(n_fft, periodic=True)
+    if kind == "hann":
+        return base
+    if kind == "sqrthann":
+        return base.sqrt()
+    raise NotImplementedError(f"Window type {kind} not implemented!")
+
+
 class SpecTransform:
     def __init__(self, n_fft=510, hop_length=128, window="hann", spec_factor=0.15, spec_abs_exponent=0.5,
-                 transform_type="exponent", **ignored):
-        self.n_fft = n_fft
-        self.hop_length = hop_length
-        if window == "hann":
-            self.window = torch.hann_window(n_fft, periodic=True)
-        elif window == "sqrthann":
-            self.window = torch.sqrt(torch.hann_window(n_fft, periodic=True))
-        else:
-            raise NotImplementedError(f"Window type {window} not implemented!")
-        self.windows = {}
-        self.spec_factor = spec_factor
-        self.spec_abs_exponent = spec_abs_exponent
+                 transform_type="exponent", **_unused):
+        if transform_type not in ("exponent", "log", "none"):
+            raise ValueError(f"unknown transform_type {transform_type!r}")
+        self.n_fft, self.hop_length = n_fft, hop_length
+        self.window = _window(window, n_fft)
+        self._win_cache = {}
+        self.spec_factor, self.spec_abs_exponent = spec_factor, spec_abs_exponent
         self.transform_type = transform_type
 
-    def _get_window(self, x):
-        w = self.windows.get(x.device)
-        if w is None:
-            w = self.window.to(x.device)
-            self.windows[x.device] = w
-        return w
+    def _win(self, ref):
+        if ref.device not in self._win_cache:
+            self._win_cache[ref.device] = self.window.to(ref.device)
+        return self._win_cache[ref.device]
+
+    # ---- magnitude warping, phase preserved ---------------------------------------------------
+    @staticmethod
+    def _remag(spec, new_mag):
+        return torch.polar(new_mag, spec.angle())
 
     def spec_fwd(self, spec):
-        if self.transform_type == "exponent":
-            if self.spec_abs_exponent != 1:
-                e = self.spec_abs_exponent
-                spec = spec.abs() ** e * torch.exp(1j * spec.angle())
-            spec = spec * self.spec_factor
-        elif self.transform_type == "log":
-            spec = torch.log(1 + spec.abs()) * torch.exp(1j * spec.angle())
-            spec = spec * self.spec_factor
-        return spec
+        kind, c = self.transform_type, self.spec_factor
+        if kind == "none":
+            return spec
+        if kind == "log":
+            return c * self._remag(spec, torch.log1p(spec.abs()))
+        e = self.spec_abs_exponent
+        return c * (spec if e == 1 else self._remag(spec, spec.abs().pow(e)))
 
     def spec_back(self, spec):
-        if self.transform_type == "exponent":
-            spec = spec / self.spec_factor
-            if self.spec_abs_exponent != 1:
-                e = self.spec_abs_exponent
-                spec = spec.abs() ** (1 / e) * torch.exp(1j * spec.angle())
-        elif self.transform_type == "log":
-            spec = spec / self.spec_factor
-            spec = (torch.exp(spec.abs()) - 1) * torch.exp(1j * spec.angle())
-        return spec
+        kind = self.transform_type
+        if kind == "none":
+            return spec
+        spec = spec / self.spec_factor
+        if kind == "log":
+            return self._remag(spec, torch.expm1(spec.abs()))
+        e = self.spec_abs_exponent
+        return spec if e == 1 else self._remag(spec, spec.abs().pow(1.0 / e))
+
+    # ---- STFT pair ------------------------------------------------------------------------------
+    def _stft_args(self, ref):
+        return dict(n_fft=self.n_fft, hop_length=self.hop_length, window=self._win(ref), center=True)
 
     def stft(self, sig):
-        return torch.stft(sig, n_fft=self.n_fft, hop_length=self.hop_length, window=self._get_window(sig),
-                          center=True, return_complex=True)
+        return torch.stft(sig, return_complex=True, **self._stft_args(sig))
 
     def istft(self, spec, length=None):
-        return torch.istft(spec, n_fft=self.n_fft, hop_length=self.hop_length, window=self._get_window(spec),
-                           center=True, length=length)
+        return torch.istft(spec, length=length, **self._stft_args(spec))

@@ -223,6 +223,14 @@ def main():
     Yp = c64(synth.synth_spectrogram(0, 1, 256, 501))
     save("op_pad_spec", shape=np.array(pad_spec(Yp).shape), tail=pad_spec(Yp)[..., 501:].abs().sum())
 
+    # ---- spectrogram transforms either side of the path (data_module.py:149-205) -------------
+    from flowmse.data_module import SpecsDataModule
+    dm = SpecsDataModule(base_dir="")
+    sig = torch.from_numpy(synth.normal(5, 8, (1, 4000), 0.1))
+    S = dm.stft(sig)
+    Sf = dm.spec_fwd(S)
+    save("op_spec", stft=S, fwd=Sf, back=dm.spec_back(Sf), istft=dm.istft(dm.spec_back(Sf), 4000))
+
     # ---- tiny net: forward + sampler --------------------------------------------
     tiny = load_synth(NCSNpp(**TINY)).eval()
     B, Fq, T = 2, 64, 64

@@ -193,3 +193,18 @@ def test_config0_cpu_plumbing_with_oracle_field():
     assert out.shape == (64000,) and np.isfinite(out).all()
     r = energy_ratios(out + 1e-3, sig[0].numpy(), sig[0].numpy() * 0.1 + 1e-3)
     assert all(np.isfinite(v) for v in r)
+
+
+def test_spec_transform_matches_reference_golden():
+    """STFT / spec_fwd / spec_back / iSTFT against the reference's SpecsDataModule (tests/golden/op_spec.npz)."""
+    from flowmse_amd.data_module import SpecTransform
+    g = Cs.gold("op_spec")
+    st = SpecTransform()
+    sig = torch.from_numpy(Cs.synth.normal(5, 8, (1, 4000), 0.1))
+    S = st.stft(sig)
+    assert S.shape == tuple(g["stft"].shape) and S.shape[1] == 256
+    assert Cs.rel_l2(S, g["stft"]) < 1e-6
+    Sf = st.spec_fwd(S)
+    assert Cs.rel_l2(Sf, g["fwd"]) < 1e-6
+    assert Cs.rel_l2(st.spec_back(Sf), g["back"]) < 1e-5
+    assert Cs.rel_l2(st.istft(st.spec_back(Sf), 4000), g["istft"]) < 1e-5
