@@ -217,6 +217,16 @@ def main():
             table = model.dnn.profile_end()
             tot = sum(v["ms"] for v in table.values())
             print(f"# per-op GPU time, one step ({tot:.2f} ms in kernels)", file=sys.stderr)
+            import collections
+            import re as _re
+            lev = collections.defaultdict(lambda: [0, 0.0])
+            for k, v in table.items():
+                mres = _re.search(r"@(\d+)x(\d+)", k)
+                key = mres.group(1) if mres else "other"
+                lev[key][0] += v["launches"]
+                lev[key][1] += v["ms"]
+            for k in sorted(lev, key=lambda q: -lev[q][1]):
+                print(f"# level H={k:6s} launches={lev[k][0]:5d} {lev[k][1]:8.2f} ms {100*lev[k][1]/tot:5.1f}%", file=sys.stderr)
             for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
                 tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0
                 gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0

@@ -507,7 +507,7 @@ struct Builder {
             pnblk[k] = nblk;
             temp[k] = true;
             const size_t t_off = src[k]->off, p_off = poff[k];
-            op("gn_stats", [=](hipStream_t s) {
+            op("gn_stats@" + std::to_string(src[k]->H) + "x" + std::to_string(src[k]->W), [=](hipStream_t s) {
                 return launch_gn_stats(M->A(t_off), Ck, nullptr, 0, Bn, HW, M->A(p_off), nblk, s);
             }, 3.0 * Bn * HW * Ck, 4.0 * Bn * HW * Ck);
         }
@@ -518,7 +518,7 @@ struct Builder {
         const size_t gm = g.mean, gs = g.scale, p0 = poff[0], p1 = poff[1];
         const int n0 = pnblk[0], n1 = pnblk[1];
         const bool has2 = b2 != nullptr;
-        op("gn_finalize", [=](hipStream_t s) {
+        op("gn_finalize@" + std::to_string(a.H) + "x" + std::to_string(a.W), [=](hipStream_t s) {
             return launch_gn_finalize(M->A(p0), n0, C1, has2 ? M->A(p1) : nullptr, n1, C2, Bn, HW, G, M->W(w_gamma),
                                       1e-6f, M->A(gm), M->A(gs), s);
         });
@@ -536,7 +536,7 @@ struct Builder {
         Tn o = alloc(a.H, a.W, C1 + C2);
         const size_t a_off = a.off, b_off = b2 ? b2->off : 0, o_off = o.off;
         const bool has2 = b2 != nullptr;
-        op("gn_apply", [=](hipStream_t s) {
+        op("gn_apply@" + std::to_string(a.H) + "x" + std::to_string(a.W), [=](hipStream_t s) {
             GnParams p{M->A(g.mean), M->A(g.scale), M->W(g.beta)};
             return launch_gn_apply(M->A(a_off), C1, has2 ? M->A(b_off) : nullptr, C2, Bn, HW, p, silu ? 1 : 0,
                                    M->A(o_off), s);
@@ -606,7 +606,7 @@ struct Builder {
             return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s, false);
         }, flops, in_bytes + (ks > 1 ? part_bytes : out_bytes), has_gin && Cout > 64);
         if (ks > 1)
-            op("splitk_reduce", [=](hipStream_t s) { return launch_splitk_reduce(make_args(), s); }, 0.0,
+            op("splitk_reduce@" + std::to_string(H) + "x" + std::to_string(Wd), [=](hipStream_t s) { return launch_splitk_reduce(make_args(), s); }, 0.0,
                part_bytes + out_bytes);
         if (ks > 1) arena.release(part_off);
         return o;
@@ -620,7 +620,7 @@ struct Builder {
         const size_t a_off = a.off, o_off = o.off, add_off = add ? add->off : 0;
         const bool hasg = g != nullptr, hasadd = add != nullptr;
         GnBuf gb = hasg ? *g : GnBuf();
-        op(up ? "fir_up" : "fir_down", [=](hipStream_t s) {
+        op(std::string(up ? "fir_up@" : "fir_down@") + std::to_string(H) + "x" + std::to_string(Wd), [=](hipStream_t s) {
             GnParams p{nullptr, nullptr, nullptr};
             if (hasg) p = GnParams{M->A(gb.mean), M->A(gb.scale), M->W(gb.beta)};
             if (up)
@@ -691,7 +691,7 @@ struct Builder {
         release(hn);
         Tn o = alloc(x.H, x.W, C);
         const size_t q_off = qkv.off, o_off = o.off;
-        op("attention", [=](hipStream_t s) { return launch_attention(M->A(q_off), Bn, L, C, M->A(o_off), s); },
+        op("attention@" + std::to_string(x.H) + "x" + std::to_string(x.W), [=](hipStream_t s) { return launch_attention(M->A(q_off), Bn, L, C, M->A(o_off), s); },
            4.0 * Bn * (double)L * L * C, 16.0 * Bn * L * C);
         release(qkv);
         Tn out = conv("attn_out", o, nullptr, mod.w_o, mod.w_o_b, -1, C, 1, &x, rs2);
