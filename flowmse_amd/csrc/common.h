@@ -36,6 +36,51 @@ struct GnParams {
     const float* beta;   // [C]
 };
 
+// ------------------------------------------------------------------ GroupNorm partial statistics
+// Every producer of a tensor that a GroupNorm will consume emits, per (sample, pixel block, channel), the block's
+// MEAN and its centred second moment M2 = sum (x - mean)^2 -- never raw sum / sum of squares, whose difference
+// cancels catastrophically in fp32 when |mean| >> std.  Threads accumulate about a pivot (their first value),
+// partials are merged with Chan's parallel formula, and gn_finalize merges blocks and channels in fp64.
+// Layout: partial[((b * nblk + blk) * C + c) * 2 + {0: mean, 1: M2}], block blk covering pixels
+// [blk * ppb, min(HW, (blk + 1) * ppb)).
+struct Stat4 {
+    float4 p, s1, s2;
+    int n;
+    __device__ __forceinline__ void init() {
+        n = 0;
+        p = s1 = s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ void add(const float4& v) {
+        if (n == 0) p = v;
+        const float dx = v.x - p.x, dy = v.y - p.y, dz = v.z - p.z, dw = v.w - p.w;
+        s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+        s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
+        ++n;
+    }
+    // out8 = {mean.xyzw, M2.xyzw}
+    __device__ __forceinline__ void finish(float* out8) const {
+        const float inv = n > 0 ? 1.f / (float)n : 0.f;
+        const float a[4] = {s1.x, s1.y, s1.z, s1.w}, q[4] = {s2.x, s2.y, s2.z, s2.w}, pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            out8[j] = pv[j] + a[j] * inv;
+            out8[4 + j] = fmaxf(q[j] - a[j] * a[j] * inv, 0.f);
+        }
+    }
+};
+// merge block B (nB, meanB, M2B) into A, per channel of a quad; acc8 / in8 = {mean.xyzw, M2.xyzw}
+__device__ __forceinline__ void chan_merge4(float& nA, float* acc8, float nB, const float* in8) {
+    if (nB <= 0.f) return;
+    const float n = nA + nB, w = nB / n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float d = in8[j] - acc8[j];
+        acc8[j] += d * w;
+        acc8[4 + j] += in8[4 + j] + d * d * nA * w;
+    }
+    nA = n;
+}
+
 // ------------------------------------------------------------------ conv (implicit GEMM, MFMA fp32)
 struct ConvArgs {
     const float* in1;   // [B][H][W][C1]
@@ -91,6 +136,7 @@ int launch_conv_cin4(const ConvArgs& a, hipStream_t s);
 // ------------------------------------------------------------------ GroupNorm
 // stats over (C/G channels) x H x W for a (possibly concatenated) NHWC tensor
 int gn_partial_blocks(int HW, int C);
+int gn_pixels_per_block(int HW, int nblk);      // ceil(HW / nblk): the block size every producer uses
 int launch_gn_stats(const float* in1, int C1, const float* in2, int C2, int B, int HW,
                     float* partial /*[B][nblk][C][2]*/, int nblk, hipStream_t s);
 // statistics may come as two partial sets (channel concat of two tensors whose partials were produced
@@ -98,6 +144,7 @@ int launch_gn_stats(const float* in1, int C1, const float* in2, int C2, int B, i
 int launch_gn_finalize(const float* partial1, int nblk1, int C1, const float* partial2, int nblk2, int C2, int B,
                        int HW, int G, const float* gamma, float eps, float* mean /*[B][C]*/,
                        float* scale /*[B][C]*/, hipStream_t s);
+
 int launch_gn_apply(const float* in1, int C1, const float* in2, int C2, int B, int HW,
                     GnParams gn, int silu, float* out, hipStream_t s);
 

@@ -84,7 +84,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + n);
         const bool has_b2 = a.bias2 != nullptr, has_res = a.res != nullptr;
-        float4 st_s = make_float4(0.f, 0.f, 0.f, 0.f), st_q = make_float4(0.f, 0.f, 0.f, 0.f);
+        Stat4 st;
+        st.init();
 #pragma unroll 4
         for (int rr = er0; rr < BM; rr += RPP) {
             const int m = rowW ? m0 + (rr >> 4) * rowW + (rr & 15) : m0 + rr;
@@ -102,28 +103,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
             }
             v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
             *reinterpret_cast<float4*>(a.out + o) = v;
-            st_s.x += v.x; st_s.y += v.y; st_s.z += v.z; st_s.w += v.w;
-            st_q.x = fmaf(v.x, v.x, st_q.x); st_q.y = fmaf(v.y, v.y, st_q.y);
-            st_q.z = fmaf(v.z, v.z, st_q.z); st_q.w = fmaf(v.w, v.w, st_q.w);
+            st.add(v);
         }
         if (a.stats) {
             // Fused GroupNorm statistics of the tile just written (launch guarantees: tile inside one sample, all
             // BM rows valid).  Threads tid and tid+32 of a wave own the same channel quad when C4 == 32; in general
             // threads with equal ec4 are reduced through the free tail of the LDS block.
             float* red = smem + BM * CROW;                       // [NT / C4][C4][8] floats
-            float* mine = red + (er0 * C4 + ec4) * 8;
-            mine[0] = st_s.x; mine[1] = st_s.y; mine[2] = st_s.z; mine[3] = st_s.w;
-            mine[4] = st_q.x; mine[5] = st_q.y; mine[6] = st_q.z; mine[7] = st_q.w;
+            st.finish(red + (er0 * C4 + ec4) * 8);                  // every thread covers BM / RPP rows
         }
     }
     if (a.stats) {
         __syncthreads();
         if (n < a.Cout && er0 == 0) {
             const float* red = smem + BM * CROW;
-            float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int r = 0; r < RPP; ++r)
+            float acc8[8], nacc = (float)(BM / RPP);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc8[j] += red[(r * C4 + ec4) * 8 + j];
+            for (int j = 0; j < 8; ++j) acc8[j] = red[ec4 * 8 + j];
+            for (int r = 1; r < RPP; ++r) chan_merge4(nacc, acc8, (float)(BM / RPP), red + (r * C4 + ec4) * 8);
             const int bsmp = m0 / HW;
             int tile = (m0 - bsmp * HW) / BM;
             if (rowW) {                       // 8x16 tiles, row-major over the image
@@ -712,7 +709,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(ConvArgs a, in
     const int b = blockIdx.y, blk = blockIdx.x;
     const int n = cq * 4;
     const int64_t slice = (int64_t)a.B * HW * a.Cout;
-    float4 st_s = make_float4(0.f, 0.f, 0.f, 0.f), st_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    Stat4 st;
+    st.init();
     if (pr < PR) {
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + n);
@@ -735,22 +733,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(ConvArgs a, in
             }
             v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
             *reinterpret_cast<float4*>(a.out + i4) = v;
-            st_s.x += v.x; st_s.y += v.y; st_s.z += v.z; st_s.w += v.w;
-            st_q.x = fmaf(v.x, v.x, st_q.x); st_q.y = fmaf(v.y, v.y, st_q.y);
-            st_q.z = fmaf(v.z, v.z, st_q.z); st_q.w = fmaf(v.w, v.w, st_q.w);
+            st.add(v);
         }
     }
     float* mine = red + tid * 8;
-    mine[0] = st_s.x; mine[1] = st_s.y; mine[2] = st_s.z; mine[3] = st_s.w;
-    mine[4] = st_q.x; mine[5] = st_q.y; mine[6] = st_q.z; mine[7] = st_q.w;
+    st.finish(mine);
     __syncthreads();
     if (pr == 0) {
-        float acc8[8];
+        float acc8[8], nacc = (float)st.n;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc8[j] = mine[j];
-        for (int r = 1; r < PR; ++r)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc8[j] += red[(r * Q + cq) * 8 + j];
+        for (int r = 1; r < PR; ++r) {
+            const int cnt = r < PB ? (PB - r + PR - 1) / PR : 0;         // pixels lane r visited
+            chan_merge4(nacc, acc8, (float)cnt, red + (r * Q + cq) * 8);
+        }
         float* dst = a.stats + (((int64_t)b * a.stats_nblk + blk) * a.Cout + n) * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

@@ -19,6 +19,8 @@ namespace flowse {
 
 constexpr int GN_THREADS = 256;
 
+int gn_pixels_per_block(int HW, int nblk) { return (HW + nblk - 1) / nblk; }
+
 int gn_partial_blocks(int HW, int C) {
     // <= 256 pixels per block (enough blocks in flight to stream at HBM rate), at most 512 per sample
     int nblk = (HW + 255) / 256;
@@ -28,19 +30,20 @@ int gn_partial_blocks(int HW, int C) {
     return nblk;
 }
 
-// grid (nblk, B).  Q = C/4 channel quads; PR = 256 / Q pixel lanes (Q <= 256).
+// grid (nblk, B).  Q = C/4 channel quads; PR = 256 / Q pixel lanes (Q <= 256).  Block blk covers pixels
+// [blk * per, min(HW, (blk + 1) * per)) and writes (mean, M2) per channel (see Stat4 in common.h).
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __restrict__ in1, int C1,
                                                               const float* __restrict__ in2, int C2, int HW,
-                                                              float* __restrict__ partial, int nblk) {
+                                                              float* __restrict__ partial, int nblk, int per) {
     __shared__ float red[GN_THREADS * 8];
     const int C = C1 + C2, Q = C >> 2;
     const int PR = GN_THREADS / Q;
     const int tid = threadIdx.x;
     const int pr = tid / Q, cq = tid - pr * Q;
     const int b = blockIdx.y, blk = blockIdx.x;
-    const int per = (HW + nblk - 1) / nblk;
     const int p0 = blk * per, p1 = min(HW, p0 + per);
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+    Stat4 st;
+    st.init();
     if (pr < PR) {
         const int c = cq * 4;
         const float* src;
@@ -48,58 +51,62 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __res
         if (c < C1) { src = in1; cs = C1; cc = c; } else { src = in2; cs = C2; cc = c - C1; }
         src += (int64_t)b * HW * cs + cc;
 #pragma unroll 4
-        for (int p = p0 + pr; p < p1; p += PR) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)p * cs);
-            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-            ss[0] = fmaf(v.x, v.x, ss[0]); ss[1] = fmaf(v.y, v.y, ss[1]);
-            ss[2] = fmaf(v.z, v.z, ss[2]); ss[3] = fmaf(v.w, v.w, ss[3]);
-        }
+        for (int p = p0 + pr; p < p1; p += PR) st.add(*reinterpret_cast<const float4*>(src + (int64_t)p * cs));
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = s[j]; red[tid * 8 + 4 + j] = ss[j]; }
+    st.finish(red + tid * 8);
     __syncthreads();
-    // reduce over pixel lanes: thread (0, cq) sums rows 1..PR-1
     if (pr == 0) {
-        for (int r = 1; r < PR; ++r) {
-            const float* o = red + (r * Q + cq) * 8;
+        float acc8[8], nacc = (float)st.n;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s[j] += o[j]; ss[j] += o[4 + j]; }
+        for (int j = 0; j < 8; ++j) acc8[j] = red[tid * 8 + j];
+        const int len = p1 - p0;
+        for (int r = 1; r < PR; ++r) {
+            const int cnt = r < len ? (len - r + PR - 1) / PR : 0;
+            chan_merge4(nacc, acc8, (float)cnt, red + (r * Q + cq) * 8);
         }
         float* dst = partial + (((int64_t)b * nblk + blk) * C + cq * 4) * 2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { dst[2 * j] = s[j]; dst[2 * j + 1] = ss[j]; }
+        for (int j = 0; j < 4; ++j) { dst[2 * j] = acc8[j]; dst[2 * j + 1] = acc8[4 + j]; }
     }
 }
 
-// grid (G, B), 64 threads.  Channels [0,C1) take their partials from set 1, [C1,C1+C2) from set 2.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ p1, int nblk1, int C1,
-                                                         const float* __restrict__ p2, int nblk2, int C2, int HW,
-                                                         int G, const float* __restrict__ gamma, float eps,
+// grid (G, B), 64 threads.  Channels [0,C1) take their partials from set 1 (ppb1 pixels per block), [C1,C1+C2) from
+// set 2.  Blocks and channels are merged with Chan's formula in fp64: mean and biased variance of the group.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ p1, int nblk1, int ppb1, int C1,
+                                                         const float* __restrict__ p2, int nblk2, int ppb2, int C2,
+                                                         int HW, int G, const float* __restrict__ gamma, float eps,
                                                          float* __restrict__ mean, float* __restrict__ scale) {
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int C = C1 + C2;
     const int cpg = C / G;
-    double s = 0.0, ss = 0.0;
+    double n = 0.0, mu = 0.0, m2 = 0.0;
     for (int j = 0; j < cpg; ++j) {
         const int c = g * cpg + j;
         const bool first = c < C1;
         const float* p = first ? p1 : p2;
         const int nblk = first ? nblk1 : nblk2, Cs = first ? C1 : C2, cc = first ? c : c - C1;
+        const int ppb = first ? ppb1 : ppb2;
         for (int blk = lane; blk < nblk; blk += 64) {
             const float* q = p + (((int64_t)b * nblk + blk) * Cs + cc) * 2;
-            s += (double)q[0];
-            ss += (double)q[1];
+            const double nb = (double)min(ppb, HW - blk * ppb);
+            const double d = (double)q[0] - mu, nn = n + nb;
+            mu += d * nb / nn;
+            m2 += (double)q[1] + d * d * n * nb / nn;
+            n = nn;
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o);
-        ss += __shfl_xor(ss, o);
+        const double nb = __shfl_xor(n, o), mb = __shfl_xor(mu, o), qb = __shfl_xor(m2, o);
+        const double nn = n + nb;
+        if (nn > 0.0) {
+            const double d = mb - mu;
+            mu += d * nb / nn;
+            m2 += qb + d * d * n * nb / nn;
+            n = nn;
+        }
     }
-    const double cnt = (double)HW * cpg;
-    const double mu = s / cnt;
-    double var = ss / cnt - mu * mu;
-    if (var < 0.0) var = 0.0;
+    const double var = m2 / n;                      // n == HW * cpg
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float muf = (float)mu;
     if (lane < cpg) {
@@ -143,20 +150,23 @@ int launch_gn_stats(const float* in1, int C1, const float* in2, int C2, int B, i
         set_error("gn_stats: unsupported channels C1=%d C2=%d", C1, C2);
         return ERR_SHAPE;
     }
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(GN_THREADS), 0, s, in1, C1, in2, C2, HW, partial, nblk);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(GN_THREADS), 0, s, in1, C1, in2, C2, HW, partial, nblk,
+                       gn_pixels_per_block(HW, nblk));
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
 
 int launch_gn_finalize(const float* partial1, int nblk1, int C1, const float* partial2, int nblk2, int C2, int B,
                        int HW, int G, const float* gamma, float eps, float* mean, float* scale, hipStream_t s) {
+    // every producer cuts the HW pixels of a sample into nblk equal blocks (the last one may be short)
+    const int ppb1 = gn_pixels_per_block(HW, nblk1), ppb2 = nblk2 > 0 ? gn_pixels_per_block(HW, nblk2) : 1;
     const int C = C1 + C2;
     if (C % G != 0 || C / G > 64 || (C2 > 0 && !partial2)) {
         set_error("gn_finalize: unsupported C=%d G=%d", C, G);
         return ERR_SHAPE;
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial1, nblk1, C1, partial2, nblk2, C2, HW, G,
-                       gamma, eps, mean, scale);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial1, nblk1, ppb1, C1, partial2, nblk2, ppb2,
+                       C2, HW, G, gamma, eps, mean, scale);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }

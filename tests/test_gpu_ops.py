@@ -161,6 +161,31 @@ def test_group_norm_concat_straddle(G, c1, c2):
     assert C.rel_l2(G.group_norm(x1, g, b, x2=x2, silu=True), ref) < TOL
 
 
+@pytest.mark.parametrize("offset", [50.0, 1000.0])
+def test_group_norm_large_mean(G, offset):
+    """|mean| >> std: raw sum / sum-of-squares statistics would cancel catastrophically in fp32; the pivoted
+    mean / M2 partials must stay as accurate as a float64 evaluation of the same fp32 input allows."""
+    x = rnd(17, (2, 64, 32, 32)) + offset
+    g = 1.0 + rnd(18, (64,), 0.2)
+    b = rnd(19, (64,), 0.2)
+    ref = F.group_norm(x.double(), 16, g.double(), b.double(), eps=1e-6).float()
+    got = G.group_norm(x, g, b, silu=False)
+    # floor: the mean itself is stored in fp32 (half an ulp of 1000 is 3e-5 of one standard deviation)
+    assert C.rel_l2(got, ref) < (2e-5 if offset < 100 else 6e-5)
+    # same through the statistics fused into a conv epilogue + GroupNorm fused into the next conv's input:
+    # y = conv_b(GN(conv_a(x0)))  with conv_a producing a large-mean tensor
+    x0 = rnd(20, (2, 32, 128, 128))
+    wa = rnd(21, (128, 32, 3, 3), (1.0 / (32 * 9)) ** 0.5)
+    ba = torch.full((128,), float(offset))
+    wb = rnd(22, (128, 128, 3, 3), (1.0 / (128 * 9)) ** 0.5)
+    g2 = 1.0 + rnd(23, (128,), 0.2)
+    b2 = rnd(24, (128,), 0.2)
+    mid = F.conv2d(x0, wa, ba, padding=1)
+    ref2 = F.conv2d(F.group_norm(mid.double(), 32, g2.double(), b2.double(), eps=1e-6).float(), wb, None, padding=1)
+    got2 = G.conv3x3_gn(G.conv2d(x0, wa, ba), g2, b2, wb, None, silu=False)
+    assert C.rel_l2(got2, ref2) < 5e-5
+
+
 def test_fir_golden(G):
     g = C.gold("op_fir")
     x = torch.from_numpy(synth.normal(5, 1, (2, 8, 16, 32)))
