@@ -50,6 +50,8 @@ SIGNATURES = {
     "flowse_prior_sample": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
     "flowse_euler_sample": (_i, [_vp, _vp, _vp, C.POINTER(_f), C.POINTER(_f), _i, _i, _i, _i, _vp]),
     "flowse_axpy": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
+    "flowse_stft_compress": (_i, [_fp, _i, _i, _f, _vp, _i, _i, _f, _f, _vp]),
+    "flowse_istft_decompress": (_i, [_vp, _i, _i, _i, _f, _f, _fp, _i, _f, _vp]),
     "flowse_profile_begin": (_i, [_vp, _i]),
     "flowse_profile_end": (_i, [_vp, C.c_char_p, _i]),
     "flowse_upfirdn2d": (_i, [_fp, _fp] + [_i] * 13 + [_fp, _i, _i, _vp]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflowse_hip.so")
-SOURCES = ["model.hip", "conv_mfma.hip", "norm.hip", "fir.hip", "attention.hip", "misc.hip"]
+SOURCES = ["model.hip", "conv_mfma.hip", "norm.hip", "fir.hip", "attention.hip", "misc.hip", "spec.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"]
 

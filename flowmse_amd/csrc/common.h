@@ -177,6 +177,11 @@ int launch_linear(const float* in, int B, int K, const float* W, const float* bi
 //   mode 2: out = x + dt * v   (Euler update  x + VF * (-dt), VF = -v); out may alias x
 int launch_head(const float* pyr4, const float* t, const float* Wout /*[2][4]*/, const float* bout /*[2]*/,
                 int B, int F, int T, int mode, const float* x_c64, float dt, float* out_c64, hipStream_t s);
+// fused STFT + compression (-> complex64 [B,1,256,Tpad], frames >= T zeroed) and decompression + iSTFT
+int launch_stft_compress(const float* sig, int B, int L, float scale_in, float* out_c64, int T, int Tpad, float factor,
+                         float exponent, hipStream_t s);
+int launch_istft_decompress(const float* spec_c64, int B, int T, int Tpad, float factor, float exponent, float* out,
+                            int Lout, float scale_out, hipStream_t s);
 // out = y + sigma * z   (complex64 as float pairs)
 int launch_axpy(const float* y, const float* z, float sigma, int64_t n, float* out, hipStream_t s);
 

@@ -1123,6 +1123,26 @@ int flowse_euler_sample(flowse_model* m, void* x_inout, const void* y, const flo
     return OK;
 }
 
+int flowse_stft_compress(const float* sig, int B, int L, float scale_in, void* out_c64, int T, int Tpad, float factor,
+                         float exponent, void* stream) {
+    if (!sig || !out_c64) {
+        set_error("flowse_stft_compress: null argument");
+        return ERR_ARG;
+    }
+    return launch_stft_compress(sig, B, L, scale_in, static_cast<float*>(out_c64), T, Tpad, factor, exponent,
+                                static_cast<hipStream_t>(stream));
+}
+
+int flowse_istft_decompress(const void* spec_c64, int B, int T, int Tpad, float factor, float exponent, float* out,
+                            int Lout, float scale_out, void* stream) {
+    if (!spec_c64 || !out) {
+        set_error("flowse_istft_decompress: null argument");
+        return ERR_ARG;
+    }
+    return launch_istft_decompress(static_cast<const float*>(spec_c64), B, T, Tpad, factor, exponent, out, Lout,
+                                   scale_out, static_cast<hipStream_t>(stream));
+}
+
 int flowse_profile_begin(flowse_model* m, int mode) {
     if (!m || (mode != 0 && mode != 1)) {
         set_error("flowse_profile_begin: bad argument");

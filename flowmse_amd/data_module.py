@@ -58,6 +58,42 @@ class SpecTransform:
         e = self.spec_abs_exponent
         return spec if e == 1 else self._remag(spec, spec.abs().pow(1.0 / e))
 
+    # ---- fused HIP path (GPU tensors, reference STFT geometry) ------------------------------------
+    def fused_ok(self, ref):
+        """The HIP kernels cover the released configuration: n_fft 510, hop 128, hann, 'exponent' transform."""
+        return (ref.is_cuda and self.n_fft == 510 and self.hop_length == 128 and self.transform_type == "exponent"
+                and bool(torch.equal(self.window, torch.hann_window(510, periodic=True))))
+
+    def analyze(self, sig, scale=1.0, pad_multiple=64):
+        """pad_spec(spec_fwd(stft(sig * scale)))[:, None] in one kernel: sig float32 [B, L] on 'cuda' ->
+        complex64 [B, 1, 256, Tpad] (frames beyond L // 128 + 1 are the zero padding)."""
+        from flowmse_amd import _lib
+        sig = sig.contiguous().float()
+        B, L = sig.shape
+        T = L // self.hop_length + 1
+        Tpad = ((T + pad_multiple - 1) // pad_multiple) * pad_multiple
+        out = torch.empty(B, 1, 256, Tpad, dtype=torch.complex64, device=sig.device)
+        with torch.cuda.device(sig.device):
+            _lib.check(_lib.lib.flowse_stft_compress(_lib.ptr(sig), B, L, float(scale), _lib.ptr(out), T, Tpad,
+                                                     float(self.spec_factor), float(self.spec_abs_exponent),
+                                                     _lib.current_stream()))
+        return out
+
+    def synthesize(self, spec, length, scale=1.0):
+        """istft(spec_back(spec), length) * scale in one kernel: spec complex64 [B, 1, 256, Tpad] -> [B, length].
+        Like the reference (model.py:190-191 on the padded sample), ALL Tpad frames take part in the overlap-add:
+        the frames past length // 128 + 1 still reach the last samples of the waveform."""
+        from flowmse_amd import _lib
+        spec = spec.contiguous()
+        B, _, F, Tpad = spec.shape
+        T = Tpad
+        out = torch.empty(B, length, dtype=torch.float32, device=spec.device)
+        with torch.cuda.device(spec.device):
+            _lib.check(_lib.lib.flowse_istft_decompress(_lib.ptr(spec), B, T, Tpad, float(self.spec_factor),
+                                                        float(self.spec_abs_exponent), _lib.ptr(out), length,
+                                                        float(scale), _lib.current_stream()))
+        return out
+
     # ---- STFT pair ------------------------------------------------------------------------------
     def _stft_args(self, ref):
         return dict(n_fft=self.n_fft, hop_length=self.hop_length, window=self._win(ref), center=True)

@@ -47,12 +47,19 @@ def enhance_waveform(model, y, N=5, T_rev=1.0, t_eps=0.03, odesolver="euler", z=
     device = device or y.device
     T_orig = y.size(1)
     norm_factor = y.abs().max().item()
-    y = y / norm_factor
-    Y = torch.unsqueeze(model._forward_transform(model._stft(y.to(device))), 0)
-    Y = pad_spec(Y)
+    dm = model.data_module
+    fused = VF_fn is None and hasattr(dm, "fused_ok") and dm.fused_ok(y.to(device))
+    if fused:                      # STFT + compression + frame padding as one HIP kernel
+        Y = dm.analyze(y.to(device), 1.0 / norm_factor)
+    else:
+        y = y / norm_factor
+        Y = torch.unsqueeze(model._forward_transform(model._stft(y.to(device))), 0)
+        Y = pad_spec(Y)
     sampler = get_white_box_solver(odesolver, model.ode, VF_fn if VF_fn is not None else model, Y=Y, Y_prior=Y,
                                    T_rev=T_rev, t_eps=t_eps, N=N, z=z)
     sample, _ = sampler()
+    if fused:                      # decompression + iSTFT + rescale as one HIP kernel
+        return dm.synthesize(sample, T_orig, norm_factor).squeeze().cpu().numpy()
     x_hat = model.to_audio(sample.squeeze(), T_orig)
     return (x_hat * norm_factor).squeeze().cpu().numpy()
 

@@ -77,3 +77,27 @@ def gather_spectrograms(local, local_ids, n_total, group=None):
             if i >= 0:
                 out[i] = torch.view_as_complex(all_pay[r][k, :, :t].contiguous()).cpu()
     return out
+
+
+def enhance_sharded(sample_fn, specs, max_batch=8, group=None, pad_multiple=64):
+    """Enhance a ragged set of utterances data-parallel over the ranks of `group` (BASELINE config 4).
+
+    specs: list of complex64 spectrograms [F, T_i] (every rank holds the same list, or at least the entries of its
+    own shard); sample_fn(Y, ids) -> X maps a zero-padded batch Y [b,1,F,T] of equal padded length to the enhanced
+    batch (ids = global utterance indices of the rows, e.g. to pick reproducible noise).  Utterances are dealt to
+    ranks by padded length (LPT), batched by equal padded length, enhanced, cropped back to T_i and gathered to
+    rank 0 with ONE exchange at the very end.  Returns the list of enhanced [F, T_i] tensors on rank 0, None elsewhere.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    true_len = [int(s.shape[-1]) for s in specs]
+    padded = [((t + pad_multiple - 1) // pad_multiple) * pad_multiple for t in true_len]
+    mine = shard_utterances(padded, world)[rank]
+    out_local, ids_local = [], []
+    for T, ids in batches_by_length(mine, padded, max_batch):
+        Y = torch.stack([torch.nn.functional.pad(specs[i], (0, T - true_len[i])) for i in ids])[:, None]
+        X = sample_fn(Y.contiguous(), ids)
+        for row, i in enumerate(ids):
+            out_local.append(X[row, 0, :, :true_len[i]])
+            ids_local.append(i)
+    return gather_spectrograms(out_local, ids_local, len(specs), group=group)

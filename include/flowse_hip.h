@@ -111,6 +111,18 @@ int flowse_euler_sample(flowse_model* m, void* x_inout, const void* y, const flo
 /* One generic explicit update from a caller-held slope: x <- x + dt * k (complex64 as float pairs). */
 int flowse_axpy(const void* x, const void* k, float dt, void* out, int64_t numel_complex, void* stream);
 
+/* ---- spectrogram transforms either side of the sampler -------------------------------------
+ * flowse_stft_compress: sig float32 [B][L] -> complex64 [B,1,256,Tpad].  Equals pad_spec(spec_fwd(stft(sig * scale_in)))
+ * of the reference (data_module.py:149-162,199-201; util/other.py:83-90) for n_fft 510, hop 128, periodic hann,
+ * center=True (reflect): T = L / 128 + 1 frames, frames T..Tpad-1 are zero.  spec_fwd = factor * |z|^exponent *
+ * exp(j arg z) (transform_type "exponent"; exponent 1 = plain scaling).
+ * flowse_istft_decompress: the inverse chain istft(spec_back(spec), length = Lout) * scale_out
+ * (data_module.py:164-175,203-205; model.py:190-191) on the first T frames of the padded spectrogram. */
+int flowse_stft_compress(const float* sig, int B, int L, float scale_in, void* out_c64, int T, int Tpad, float factor,
+                         float exponent, void* stream);
+int flowse_istft_decompress(const void* spec_c64, int B, int T, int Tpad, float factor, float exponent, float* out,
+                            int Lout, float scale_out, void* stream);
+
 /* ---- in-library kernel timing (used by bench.py for the live roofline figure) -------------------------
  * Between _begin and _end every selected launch of this handle is bracketed by HIP events on the launch
  * stream.  mode 0: only launches of the dominant kernel (conv3x3_halo_kernel<2,2,2,2,true>: 3x3 conv, 128x128

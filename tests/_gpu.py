@@ -124,3 +124,25 @@ def conv3x3_gn(x1, gamma, beta, w, bias=None, x2=None, bias2=None, res=None, sca
                                       stream()))
     torch.cuda.synchronize()
     return nchw(out)
+
+
+def stft_compress(sig, scale=1.0, factor=0.15, exponent=0.5, pad_multiple=64):
+    B, Ls = sig.shape
+    T = Ls // 128 + 1
+    Tpad = ((T + pad_multiple - 1) // pad_multiple) * pad_multiple
+    a = sig.contiguous().cuda().float()
+    out = torch.empty(B, 1, 256, Tpad, dtype=torch.complex64, device="cuda")
+    _lib.check(L.flowse_stft_compress(_lib.ptr(a), B, Ls, float(scale), _lib.ptr(out), T, Tpad, factor, exponent,
+                                      stream()))
+    torch.cuda.synchronize()
+    return out.cpu(), T
+
+
+def istft_decompress(spec, T, length, scale=1.0, factor=0.15, exponent=0.5):
+    a = spec.contiguous().cuda()
+    B, _, F, Tpad = a.shape
+    out = torch.empty(B, length, device="cuda")
+    _lib.check(L.flowse_istft_decompress(_lib.ptr(a), B, T, Tpad, factor, exponent, _lib.ptr(out), length,
+                                         float(scale), stream()))
+    torch.cuda.synchronize()
+    return out.cpu()

@@ -238,3 +238,31 @@ def test_gfp_golden(G):
     W = torch.from_numpy(synth.synth_param("gfp.W", (16,)))
     got = G.gfp(torch.from_numpy(g["t"]), W)
     assert float((got - torch.from_numpy(g["out"])).abs().max()) < 2e-6
+
+
+def test_stft_istft_fused_vs_reference_golden(G):
+    """Fused STFT+compression / decompression+iSTFT kernels against the reference's SpecsDataModule outputs."""
+    g = C.gold("op_spec")
+    sig = torch.from_numpy(synth.normal(5, 8, (1, 4000), 0.1))
+    Y, T = G.stft_compress(sig)
+    assert T == g["fwd"].shape[-1] == 32 and Y.shape == (1, 1, 256, 64)
+    assert C.rel_l2(Y[0, 0, :, :T], g["fwd"][0]) < 1e-5
+    assert float(Y[0, 0, :, T:].abs().max()) == 0.0                     # pad_spec zeros
+    back = G.istft_decompress(Y, T, 4000)
+    assert C.rel_l2(back, g["istft"]) < 2e-5
+    assert C.rel_l2(back, sig) < 2e-5                                   # the chain is an identity
+
+
+@pytest.mark.parametrize("Ls,scale", [(16000, 1.0), (64000, 0.37), (12345, 2.5)])
+def test_stft_istft_fused_vs_torch(G, Ls, scale):
+    """Other lengths (incl. one that is not a multiple of the hop) and the waveform normalisation factor."""
+    from flowmse_amd.data_module import SpecTransform
+    st = SpecTransform()
+    sig = rnd(60, (2, Ls), 0.2)
+    ref = st.spec_fwd(st.stft(sig * scale))
+    Y, T = G.stft_compress(sig, scale)
+    assert T == ref.shape[-1]
+    assert C.rel_l2(Y[:, 0, :, :T], ref) < 1e-5
+    ref_back = st.istft(st.spec_back(ref), Ls) * (1.0 / scale)
+    back = G.istft_decompress(Y, T, Ls, 1.0 / scale)
+    assert C.rel_l2(back, ref_back) < 2e-5
