@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--nsolver", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16", "fp16"],
                     help="matrix-core operand mode of the large 3x3 convs (default: exact fp32)")
     ap.add_argument("--no-alt", action="store_true", help="skip the bf16x3 / bf16 operand-mode legs")
     ap.add_argument("--profile-all", action="store_true", help="per-op timing table to stderr (extra untimed pass)")
@@ -180,7 +180,8 @@ def main():
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 (3x3 convs as split-bf16 x3 MFMA, fp32 accumulate)",
-                                       "bf16": "bf16 operands in the 3x3 convs, fp32 accumulate/activations"}[args.precision],
+                                       "bf16": "bf16 operands in the 3x3 convs, fp32 accumulate/activations",
+                                       "fp16": "fp16 operands in the 3x3 convs, fp32 accumulate/activations"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"BASELINE config[1]: batch={B} synthetic complex spectrograms [{B},1,{F},{T}] per GPU, "
                                f"N={NS} Euler steps, NCSN++ (65.6M params, synthetic weights) fp32",
@@ -236,7 +237,7 @@ def main():
             # the optional operand modes of the same kernels, same workload, reported beside the exact-fp32 value
             ref_x = x.clone()
             alts = {}
-            for mode in ("bf16x3", "bf16"):
+            for mode in ("bf16x3", "bf16", "fp16"):
                 model.dnn.set_precision(mode)
                 xm = step()
                 torch.cuda.synchronize()

@@ -215,7 +215,7 @@ class NCSNpp(nn.Module):
         _lib.check(_lib.lib.flowse_model_reserve(self._handle, B, F, T, C.byref(nbytes)))
         return int(nbytes.value)
 
-    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
 
     def set_precision(self, mode):
         """'fp32' (default, exact fp32 MFMA) | 'bf16x3' (split-bf16, fp32-class) | 'bf16' (BASELINE config 3)."""

@@ -114,9 +114,10 @@ struct ConvArgs {
     // GroupNorm, residuals and all activations in HBM stay fp32.
     const void* wq = nullptr;
     int terms = 0;
+    int wq_f16 = 0;     // 1: the planes hold IEEE half instead of bf16 (terms must be 1; BASELINE config 5)
 };
 // host helper: split fp32 conv weights [Cout][Cin][3][3] into the packed bf16 planes described above
-void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst);
+void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst, bool f16 = false);
 inline int64_t conv_bf16_numel(int Cout, int Cin, int terms) { return (int64_t)Cout * 9 * Cin * (terms == 1 ? 1 : 2); }
 bool conv_supports_bf16(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // true when launch_conv will run the LDS-halo 3x3 kernel for this shape (the only one that can normalise its

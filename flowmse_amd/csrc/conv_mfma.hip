@@ -829,9 +829,12 @@ static int launch_halo(const ConvArgs& a, hipStream_t s) {
 // staged (after the fused GroupNorm+SiLU); weights are pre-split at upload.  LDS row = [hi: 32 x bf16][lo: 32 x bf16]
 // + 16 B pad (stride 144 B, or 80 B for one plane): every fragment read is a conflict-free ds_read_b128.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int TERMS, bool GN>
+// F16 = true: IEEE half operands (v_mfma_f32_32x32x16_f16, 11-bit mantissa; BASELINE config 5), TERMS must be 1.
+template <int TERMS, bool GN, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
+    static_assert(!F16 || TERMS == 1, "the half path has no split mode");
     constexpr int BN = 128, NT = 256;
     constexpr int PLANES = TERMS == 1 ? 1 : 2;
     constexpr int ROWB = PLANES * 64 + 16;               // LDS row stride in bytes
@@ -924,10 +927,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
             unsigned short hi[4], lo[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const __bf16 h = (__bf16)v[e];
-                hi[e] = __builtin_bit_cast(unsigned short, h);
-                const __bf16 l = (__bf16)(v[e] - (float)h);
-                lo[e] = __builtin_bit_cast(unsigned short, l);
+                if (F16) {
+                    const _Float16 h = (_Float16)v[e];
+                    hi[e] = __builtin_bit_cast(unsigned short, h);
+                    lo[e] = 0;
+                } else {
+                    const __bf16 h = (__bf16)v[e];
+                    hi[e] = __builtin_bit_cast(unsigned short, h);
+                    const __bf16 l = (__bf16)(v[e] - (float)h);
+                    lo[e] = __builtin_bit_cast(unsigned short, l);
+                }
             }
             rh[q].x = (unsigned)hi[0] | ((unsigned)hi[1] << 16);
             rh[q].y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
@@ -1012,11 +1021,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (TERMS == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if (F16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[i]),
+                                                                          __builtin_bit_cast(f16x8, bh[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        if (TERMS == 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1044,7 +1058,25 @@ static float bf16_to_f(unsigned short h) {
     return f;
 }
 
-void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst) {
+static unsigned short f16_rne(float f) {          // IEEE binary16, round to nearest even, overflow -> inf
+    unsigned u;
+    memcpy(&u, &f, 4);
+    const unsigned sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (unsigned short)(sign | 0x7c00u | (u > 0x7f800000u ? 0x200u : 0u));
+    if (u >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);                 // >= 65520 rounds to inf
+    if (u < 0x33000001u) return (unsigned short)sign;                              // < 2^-25 rounds to 0
+    int e = (int)(u >> 23) - 127;
+    unsigned m = (u & 0x7fffffu) | 0x800000u;
+    int shift = e < -14 ? (-14 - e) + 13 : 13;                                    // subnormal halves shift further
+    unsigned half_m = m >> shift;
+    const unsigned rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (half_m & 1u))) ++half_m;
+    unsigned out = e < -14 ? half_m : (((unsigned)(e + 15) << 10) + (half_m - 0x400u));
+    return (unsigned short)(sign | out);
+}
+
+void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst, bool f16) {
     const int planes = terms == 1 ? 1 : 2, nchunks = Cin / KC;
     for (int co = 0; co < Cout; ++co)
         for (int t = 0; t < 9; ++t)
@@ -1052,6 +1084,10 @@ void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst)
                 uint16_t* row = dst + (((int64_t)co * 9 + t) * nchunks + ch) * planes * 32;
                 for (int k = 0; k < 32; ++k) {
                     const float v = w[((int64_t)co * Cin + ch * 32 + k) * 9 + t];
+                    if (f16) {
+                        row[k] = f16_rne(v);
+                        continue;
+                    }
                     const unsigned short hi = bf16_rne(v);
                     row[k] = hi;
                     if (planes == 2) row[32 + k] = bf16_rne(v - bf16_to_f(hi));
@@ -1063,7 +1099,7 @@ bool conv_supports_bf16(int B, int H, int W, int C1, int C2, int Cout, int taps)
     return (Cout % 128) == 0 && conv_supports_fused_gn(B, H, W, C1, C2, Cout, taps);
 }
 
-template <int TERMS>
+template <int TERMS, bool F16 = false>
 static int launch_halo_bf16(const ConvArgs& a, hipStream_t s) {
     constexpr int PLANES = TERMS == 1 ? 1 : 2, ROWB = PLANES * 64 + 16;
     const int64_t M = (int64_t)a.B * a.H * a.W;
@@ -1073,16 +1109,16 @@ static int launch_halo_bf16(const ConvArgs& a, hipStream_t s) {
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static bool attr_done = false;
     if (!attr_done) {
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TERMS, false>),
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TERMS, false, F16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TERMS, true>),
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TERMS, true, F16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     if (a.gn.mean)
-        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TERMS, true>), dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TERMS, true, F16>), dim3(grid), dim3(256), lds, s, a);
     else
-        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TERMS, false>), dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TERMS, false, F16>), dim3(grid), dim3(256), lds, s, a);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
@@ -1117,9 +1153,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
     }
     if (a.ksplit <= 1 && conv_supports_fused_gn(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
         if (a.wq && (a.Cout % 128) == 0) {
-            if (a.terms == 3) return launch_halo_bf16<3>(a, s);
-            if (a.terms == 1) return launch_halo_bf16<1>(a, s);
-            set_error("conv: bf16 path needs terms = 1 or 3");
+            if (a.terms == 3 && !a.wq_f16) return launch_halo_bf16<3>(a, s);
+            if (a.terms == 1 && !a.wq_f16) return launch_halo_bf16<1>(a, s);
+            if (a.terms == 1 && a.wq_f16) return launch_halo_bf16<1, true>(a, s);
+            set_error("conv: 16-bit path needs terms = 1 (bf16 / f16) or 3 (bf16 only)");
             return ERR_ARG;
         }
         if (a.Cout <= 32) return launch_halo<4, 1, 1, 1>(a, s);

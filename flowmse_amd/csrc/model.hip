@@ -154,7 +154,7 @@ struct flowse_model {
     // device state
     float* d_w = nullptr;                  // native weight blob
     int64_t d_w_numel = 0;
-    int precision = 0;                     // 0 fp32 (exact), 1 bf16x3 split (fp32-class), 2 bf16 operands
+    int precision = 0;                     // 0 fp32 (exact), 1 bf16x3 split (fp32-class), 2 bf16, 3 fp16 operands
     uint16_t* d_wq = nullptr;              // bf16 planes of the 3x3 ResBlock convs (precision != 0)
     int64_t d_wq_numel = 0;
     char* d_ws = nullptr;                  // activation workspace
@@ -594,6 +594,7 @@ struct Builder {
             if (use_bf16) {
                 c.wq = M->d_wq + wq_off;
                 c.terms = terms;
+                c.wq_f16 = M->precision == 3 ? 1 : 0;
             }
             return c;
         };
@@ -973,8 +974,8 @@ int flowse_model_param_info(const flowse_model* m, int index, char* name, int na
 }
 
 int flowse_model_set_precision(flowse_model* m, int mode) {
-    if (!m || mode < 0 || mode > 2) {
-        set_error("flowse_model_set_precision: mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16)");
+    if (!m || mode < 0 || mode > 3) {
+        set_error("flowse_model_set_precision: mode must be 0 (fp32), 1 (bf16x3), 2 (bf16) or 3 (fp16)");
         return ERR_ARG;
     }
     if (mode != m->precision) {
@@ -1023,11 +1024,13 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
             if ((mod.in_ch % 32) == 0) {
                 mod.wq_c0 = (int64_t)q.size();
                 q.resize(q.size() + conv_bf16_numel(mod.out_ch, mod.in_ch, terms));
-                pack_conv_bf16(blob + m->params[mod.p0 + 2].offset, mod.out_ch, mod.in_ch, terms, q.data() + mod.wq_c0);
+                pack_conv_bf16(blob + m->params[mod.p0 + 2].offset, mod.out_ch, mod.in_ch, terms, q.data() + mod.wq_c0,
+                               m->precision == 3);
             }
             mod.wq_c1 = (int64_t)q.size();
             q.resize(q.size() + conv_bf16_numel(mod.out_ch, mod.out_ch, terms));
-            pack_conv_bf16(blob + m->params[mod.p0 + 8].offset, mod.out_ch, mod.out_ch, terms, q.data() + mod.wq_c1);
+            pack_conv_bf16(blob + m->params[mod.p0 + 8].offset, mod.out_ch, mod.out_ch, terms, q.data() + mod.wq_c1,
+                           m->precision == 3);
         }
         if (m->d_wq && m->d_wq_numel < (int64_t)q.size()) {
             FLOWSE_HIP(hipFree(m->d_wq));

@@ -113,7 +113,7 @@ def main(argv=None):
     ap.add_argument("--ckpt", type=str, default=None)
     ap.add_argument("--N", type=int, default=5)
     ap.add_argument("--synthetic", type=int, default=0, help="run on this many synthetic pairs with synthetic weights")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16", "fp16"])
     ap.add_argument("--batch", type=int, default=1,
                     help="enhance up to this many utterances of equal padded length per sampler call (1 = reference behaviour)")
     args = ap.parse_args(argv)

@@ -84,7 +84,8 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
 /* Matrix-core operand precision of the large 3x3 ResBlock convolutions (call BEFORE flowse_model_load_weights; a
  * change drops the uploaded weights).  0 (default): fp32 MFMA, bit-exact fp32 products.  1 "bf16x3": operands split
  * x = hi + lo in bf16, products hi*hi + hi*lo + lo*hi accumulated in fp32 (fp32-class accuracy, ~1e-5).  2 "bf16":
- * plain bf16 operands (BASELINE config 3).  Accumulation, GroupNorm, residuals and activations stay fp32. */
+ * plain bf16 operands (BASELINE config 3).  3 "fp16": IEEE half operands (BASELINE config 5).  Accumulation,
+ * GroupNorm statistics, residuals and activations stay fp32 in every mode. */
 int flowse_model_set_precision(flowse_model* m, int mode);
 
 /* Optional: plan buffers for a shape ahead of time (otherwise done lazily by the first call).
