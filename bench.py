@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--nsolver", type=int, default=5)
+    ap.add_argument("--solver", default="euler", choices=["euler", "heun", "rk4"],
+                    help="ODE solver plugin (BASELINE config 5: --solver rk4 --nsolver 25 --batch 32 --frames 1024 "
+                         "--precision fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16", "fp16"],
@@ -141,7 +144,7 @@ def main():
     ws_bytes = model.dnn.reserve(B, F, T)
 
     def step():
-        sampler = get_white_box_solver("euler", model.ode, model, Y=Y, Y_prior=Y, T_rev=1.0, t_eps=0.03, N=NS, z=Z)
+        sampler = get_white_box_solver(args.solver, model.ode, model, Y=Y, Y_prior=Y, T_rev=1.0, t_eps=0.03, N=NS, z=Z)
         x, n = sampler()
         return x
 
@@ -175,6 +178,7 @@ def main():
 
     frames_total = world * args.steps * B * T
     value = frames_total / elapsed
+    nfe_per_step = NS * {"euler": 1, "heun": 2, "rk4": 4}[args.solver]
     out = {
         "metric": "enhanced spectrogram-frames/sec at N=5 solver steps",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,11 +188,12 @@ def main():
                                        "fp16": "fp16 operands in the 3x3 convs, fp32 accumulate/activations"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"BASELINE config[1]: batch={B} synthetic complex spectrograms [{B},1,{F},{T}] per GPU, "
-                               f"N={NS} Euler steps, NCSN++ (65.6M params, synthetic weights) fp32",
+                               f"N={NS} {args.solver} steps ({nfe_per_step} NFE), NCSN++ (65.6M params, synthetic "
+                               f"weights), precision mode {args.precision}",
                    "global_batch": world * B, "frames": T, "solver_steps": NS,
                    "parallelism": f"dp{world} (per-utterance, final RCCL gather only)",
                    "workspace_GB": round(ws_bytes / 2 ** 30, 2)},
-        "achieved_TFLOPs_whole_path": value * NS * FLOP_PER_FRAME_NFE / world / 1e12,
+        "achieved_TFLOPs_whole_path": value * nfe_per_step * FLOP_PER_FRAME_NFE / world / 1e12,
     }
     if rank == 0:
         dom = prof.get("conv3x3_halo_gn_128x128")
@@ -233,7 +238,7 @@ def main():
                 gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0
                 print(f"# {k:44s} n={v['launches']:4d} {v['ms']:9.3f} ms {100*v['ms']/tot:5.1f}% "
                       f"{tf:7.1f} TF/s {gbs:8.0f} GB/s", file=sys.stderr)
-        if world == 1 and args.precision == "fp32" and not args.no_alt:
+        if world == 1 and args.precision == "fp32" and args.solver == "euler" and not args.no_alt:
             # the optional operand modes of the same kernels, same workload, reported beside the exact-fp32 value
             ref_x = x.clone()
             alts = {}

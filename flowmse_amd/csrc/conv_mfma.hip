@@ -1,21 +1,31 @@
-// 3x3 / 1x1 convolution as an implicit GEMM on the CDNA4 fp32 matrix cores.
+// 3x3 / 1x1 convolution as an implicit GEMM on the CDNA4 matrix cores.
 //
 //   out[m][n] = ( sum_{tap, ci} A[m][tap, ci] * Wp[n][tap][ci] + bias[n] + bias2[b(m)][n] + res[m][n] ) * scale
 //
-//   m = flattened NHWC pixel (b, y, x), n = output channel, K = taps * Cin with the channel axis contiguous
-//   in both operands.  Exact fp32: v_mfma_f32_32x32x2_f32 is bitwise an fmaf chain (no TF32 on gfx950).
+//   m = NHWC pixel (b, y, x), n = output channel, K = taps * Cin with the channel axis contiguous in both
+//   operands.  Default arithmetic: exact fp32 -- v_mfma_f32_32x32x2_f32 is bitwise an fmaf chain (no TF32 on
+//   gfx950).  Optional 16-bit operand modes (bf16x3 / bf16 / fp16) exist for the LDS-halo 3x3 kernel only.
 //
 // Replaces (reference): ddpm_conv3x3 / ddpm_conv1x1 (flowmse/backbones/ncsnpp_utils/layers.py:100-124) and
 // NIN (layers.py:546-555) as used by ResnetBlockBigGANpp (layerspp.py:245-274), AttnBlockpp (:75-91), the
-// progressive-output heads (ncsnpp.py:345-366) incl. the channel concat of ncsnpp.py:337 (two-source A operand)
-// and the per-sample time-embedding bias of layerspp.py:262-263 (bias2) and the (x + h)/sqrt(2) skip (res, scale).
+// progressive-output heads (ncsnpp.py:345-366) incl. the channel concat of ncsnpp.py:337 (two-source A operand),
+// the per-sample time-embedding bias of layerspp.py:262-263 (bias2), the (x + h)/sqrt(2) skip (res, scale), the
+// GroupNorm + SiLU in front of every ResBlock conv (layerspp.py:246,265; fused into the halo staging) and the
+// statistics of the NEXT GroupNorm (fused into the epilogue).
 //
-// Tiling: block = 4 waves (256 threads); wave tile = TM x TN MFMA tiles of 32x32; block tile BM x BN =
-// (WM*TM*32) x (WN*TN*32).  K is walked in steps of (tap, 32-channel chunk): the A tile [BM][32] is gathered
-// straight from the shifted NHWC pixels (zero outside the image = conv padding), the B tile [BN][32] from the
-// packed weights; both are register-staged into double-buffered LDS with a row stride of 36 floats, which
-// makes the fragment ds_read_b128 conflict-free.  Each lane reads 4 consecutive k of its row once and feeds
-// 4 successive MFMAs with them (lanes 0-31 carry k = 8j+e, lanes 32-63 carry k = 8j+4+e, for A and B alike).
+// Kernels in this file (dispatch: launch_conv):
+//   conv3x3_halo_kernel        3x3, H % 8 == 0, W % 16 == 0, C % 32 == 0, >= 256 tiles: 8x16-pixel tile, the input
+//                              halo of a 32-channel chunk staged in LDS once and shared by all nine taps, optional
+//                              fused GroupNorm+SiLU on the way in.  The production kernel (~80 % of GPU time).
+//   conv3x3_halo_bf16_kernel   the same with bf16 / bf16x3 / fp16 operands (v_mfma_f32_32x32x16_*).
+//   conv_mfma_fast_kernel      flat pixel tiling, A gathered per tap through a window buffer descriptor: 1x1 convs
+//                              and 3x3 on small images; split-K (gridDim.y) + splitk_reduce[_stats] for tiny images.
+//   conv_mfma_kernel           generic fallback (any channel count multiple of 4, chunks straddling the concat).
+//   conv_cin4_kernel           direct VALU conv for the 4-channel input layer / Combine.
+// Common tiling: block = 4 waves; wave tile = TM x TN MFMA tiles of 32x32; block tile (WM*TM*32) x (WN*TN*32);
+// K walked in steps of (tap, 32-channel chunk); operands register-staged into double-buffered LDS with a row stride
+// of 36 floats (conflict-free ds_read_b128); each lane reads 4 consecutive k of its row once and feeds 4 successive
+// MFMAs (lanes 0-31 carry k = 8j+e, lanes 32-63 carry k = 8j+4+e, for A and B alike); epilogue through LDS.
 #include <cstdlib>
 #include <cstring>
 

@@ -292,6 +292,30 @@ def test_enhance_sharded_ragged_matches_per_utterance(tiny):
         assert C.rel_l2(out[i], ref.cpu()) < 1e-5
 
 
+@pytest.mark.timeout(600)
+def test_config5_shape(full):
+    """BASELINE config 5 shape [32,1,256,1024] (32 GB workspace, 8.4 M pixels at level 0): one vector-field
+    evaluation is finite; sample 7 equals the same sample evaluated alone (batch independence, exact-fp32 mode);
+    the fp16 operand mode stays within 5e-3 of the fp32 result."""
+    B, T = 32, 1024
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.view_as_complex(torch.randn(B, 1, 256, T, 2, device="cuda", generator=g) * 0.35)
+    y = torch.view_as_complex(torch.randn(B, 1, 256, T, 2, device="cuda", generator=g) * 0.07)
+    t = torch.linspace(0.05, 1.0, B, device="cuda")
+    a = full(x, t, y)
+    assert torch.isfinite(torch.view_as_real(a)).all()
+    one = full(x[7:8].contiguous(), t[7:8].contiguous(), y[7:8].contiguous())
+    assert C.rel_l2(one.cpu(), a[7:8].cpu()) < 2e-5
+    full.dnn.set_precision("fp16")
+    try:
+        a16 = full(x, t, y)
+    finally:
+        full.dnn.set_precision("fp32")
+    err = C.rel_l2(a16.cpu(), a.cpu())
+    print("config-5 shape: fp16 mode vs fp32 mode rel-L2", err)
+    assert err < 5e-3
+
+
 def test_rejects_cpu_and_bad_shapes(tiny):
     xt, y, _ = C.tiny_inputs()
     with pytest.raises(RuntimeError):
