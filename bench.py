@@ -127,6 +127,16 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # the HIP library normally travels with the repo (built by __graft_entry__.build()); build it if it is missing
+    from flowmse_amd import build as fb
+    if not os.path.exists(fb.LIB):
+        if local_rank == 0:
+            fb.build(verbose=False)
+        else:
+            t_wait = time.time()
+            while not (os.path.exists(fb.LIB) and os.path.exists(fb.LIB + ".stamp")):
+                assert time.time() - t_wait < 600, "timed out waiting for rank 0 to build libflowse_hip.so"
+                time.sleep(1.0)
     from flowmse_amd.model import VFModel
     from flowmse_amd.sampling import get_white_box_solver
     from flowmse_amd.util import synth
