@@ -6,6 +6,11 @@ shared object is missing (build it with ``python -m flowmse_amd.build`` or ``__g
 import ctypes as C
 import os
 
+# torch FIRST: PyTorch-ROCm ships its own libamdhip64.  The library must bind to that same HIP runtime instance
+# (one runtime per process: device pointers and streams are shared with torch tensors); loaded the other way round
+# the dynamic linker would give libflowse_hip.so the system runtime and its launches would not see torch's device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libflowse_hip.so")
 
