@@ -28,6 +28,7 @@
 // MFMAs (lanes 0-31 carry k = 8j+e, lanes 32-63 carry k = 8j+4+e, for A and B alike); epilogue through LDS.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -964,17 +965,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
             if (PLANES == 2) *reinterpret_cast<uint2*>(p + 64) = make_uint2(rh[q].z, rh[q].w);
         }
     };
-    auto gloadB = [&](int s) {
+    // weight tiles travel through TWO register sets: the 16-bit MFMA phase of a step (~0.4 us) is shorter than an
+    // L2 round trip, so tile s+2 is requested while step s computes and tile s+1 (requested a step earlier) is
+    // written to LDS at the end of step s
+    u32x4 rb2[B_LOADS];
+    auto gloadB = [&](int s, u32x4 (&R)[B_LOADS]) {
         const int chunk = s / 9, tap = s - chunk * 9;
         const unsigned soff_b = (unsigned)((tap * nchunks + chunk) * (PLANES * 64));
 #pragma unroll
-        for (int q = 0; q < B_LOADS; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo[q], soff_b, 0);
+        for (int q = 0; q < B_LOADS; ++q) R[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo[q], soff_b, 0);
     };
-    auto lstoreB = [&](int buf) {
+    auto lstoreB = [&](int buf, u32x4 (&R)[B_LOADS]) {
         char* Bb = Bs + buf * BN * ROWB;
 #pragma unroll
         for (int q = 0; q < B_LOADS; ++q)
-            *reinterpret_cast<u32x4*>(Bb + (brow0 + BRPP * q) * ROWB + bcol * 16) = rb[q];
+            *reinterpret_cast<u32x4*>(Bb + (brow0 + BRPP * q) * ROWB + bcol * 16) = R[q];
     };
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -997,60 +1002,78 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
 
     const int S_all = nchunks * 9;
     gloadH(0);
-    gloadB(0);
+    gloadB(0, rb);
+    gloadB(min(1, S_all - 1), rb2);
     xformH();
     lstoreH();
-    lstoreB(0);
+    lstoreB(0, rb);
     __syncthreads();
 
-    for (int s = 0; s < S_all; ++s) {
-        const int chunk = s / 9, tap = s - chunk * 9;
-        const int buf = s & 1;
-        const bool next_chunk = chunk + 1 < nchunks;
-        if (s + 1 < S_all) gloadB(s + 1);
-        if (tap == 7 && next_chunk) gloadH(chunk + 1);
-        if (tap == 8 && next_chunk) xformH();
-        const int tapoff = ((tap / 3 - 1) * 18 + (tap - (tap / 3) * 3 - 1)) * ROWB;
-        const char* Bb = Bs + buf * BN * ROWB + (wn * 64 + li) * ROWB + kh * 16;
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh) {                   // channels 0-15 / 16-31 of the chunk
-            bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const char* p = Hs + abase[i] + tapoff + mh * 32;
-                ah[i] = *reinterpret_cast<const bf16x8*>(p);
-                if (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(p + 64);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const char* p = Bb + j * 32 * ROWB + mh * 32;
-                bh[j] = *reinterpret_cast<const bf16x8*>(p);
-                if (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(p + 64);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (F16) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[i]),
-                                                                          __builtin_bit_cast(f16x8, bh[j]), acc[i][j], 0, 0, 0);
-                    } else {
-                        if (TERMS == 3) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-                }
+    // One K step.  TAP is a literal and the nine taps of a chunk are emitted as straight-line code: no load sits
+    // under a branch, so hipcc's s_waitcnt bookkeeping stays exact (counted vmcnt, never a drain).  RL = the register
+    // set that is free (gets tile s+2), RS = the set holding tile s+1.  The next chunk's halo is requested at tap 7,
+    // normalised / split in registers at tap 8 and written after tap 8's barrier; at the last chunk the (clamped)
+    // reload of the same halo is redundant but harmless.  (A macro, not a lambda taking the sets by reference:
+    // register arrays passed through generic lambdas end up in scratch memory.)
+#define FLOWSE_STEP16(TAP, RL, RS)                                                                                   \
+    {                                                                                                                \
+        constexpr int tap = TAP;                                                                                     \
+        const int s = chunk * 9 + tap;                                                                               \
+        const int buf = s & 1;                                                                                       \
+        gloadB(min(s + 2, S_all - 1), RL);                                                                           \
+        if (tap == 7) gloadH(min(chunk + 1, nchunks - 1));                                                           \
+        if (tap == 8) xformH();                                                                                      \
+        constexpr int tapoff = ((tap / 3 - 1) * 18 + (tap % 3 - 1)) * ROWB;                                          \
+        const char* Bb = Bs + buf * BN * ROWB + (wn * 64 + li) * ROWB + kh * 16;                                     \
+        _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) {                                                           \
+            bf16x8 ah[2], al[2], bh[2], bl[2];                                                                       \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+                const char* p = Hs + abase[i] + tapoff + mh * 32;                                                    \
+                ah[i] = *reinterpret_cast<const bf16x8*>(p);                                                         \
+                if (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(p + 64);                                    \
+            }                                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+                const char* p = Bb + j * 32 * ROWB + mh * 32;                                                        \
+                bh[j] = *reinterpret_cast<const bf16x8*>(p);                                                         \
+                if (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(p + 64);                                    \
+            }                                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) {            \
+                if (F16) {                                                                                           \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[i]),             \
+                                                                      __builtin_bit_cast(f16x8, bh[j]), acc[i][j], 0, 0, 0); \
+                } else {                                                                                             \
+                    if (TERMS == 3) {                                                                                \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);       \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);       \
+                    }                                                                                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);           \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        lstoreB(buf ^ 1, RS); /* at the very last step: a spare tile into the idle buffer */                         \
+        __syncthreads();                                                                                             \
+        if (tap == 8) { /* everyone is done with this chunk's halo */                                                \
+            lstoreH();                                                                                               \
+            __syncthreads();                                                                                         \
+        }                                                                                                            \
+    }
+    // 9 steps per chunk, so the set parity alternates from chunk to chunk: two chunks per loop iteration
+    for (int c2 = 0; c2 < nchunks; c2 += 2) {
+        {
+            const int chunk = c2;
+            FLOWSE_STEP16(0, rb, rb2) FLOWSE_STEP16(1, rb2, rb) FLOWSE_STEP16(2, rb, rb2) FLOWSE_STEP16(3, rb2, rb)
+            FLOWSE_STEP16(4, rb, rb2) FLOWSE_STEP16(5, rb2, rb) FLOWSE_STEP16(6, rb, rb2) FLOWSE_STEP16(7, rb2, rb)
+            FLOWSE_STEP16(8, rb, rb2)
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < S_all) lstoreB(buf ^ 1);
-        __syncthreads();
-        if (tap == 8 && next_chunk) {
-            lstoreH();
-            __syncthreads();
+        if (c2 + 1 < nchunks) {
+            const int chunk = c2 + 1;
+            FLOWSE_STEP16(0, rb2, rb) FLOWSE_STEP16(1, rb, rb2) FLOWSE_STEP16(2, rb2, rb) FLOWSE_STEP16(3, rb, rb2)
+            FLOWSE_STEP16(4, rb2, rb) FLOWSE_STEP16(5, rb, rb2) FLOWSE_STEP16(6, rb2, rb) FLOWSE_STEP16(7, rb, rb2)
+            FLOWSE_STEP16(8, rb2, rb)
         }
     }
+#undef FLOWSE_STEP16
     conv_epilogue<2, 2, 2, 2>(a, acc, smem, m_tl, n0, M, HW, 0, W);
 }
 
