@@ -604,41 +604,46 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(ConvArgs 
     lstoreB(0);
     __syncthreads();
 
-    for (int s = 0; s < S_all; ++s) {
-        const int chunk = s / 9, tap = s - chunk * 9;
-        const int buf = s & 1;
-        const bool next_chunk = chunk + 1 < nchunks;
-        if (s + 1 < S_all) gloadB(s + 1);
-        if (tap == 7 && next_chunk) gloadH(chunk + 1);         // one step early; lands under a step of MFMA
-        if (tap == 8 && next_chunk) xformH();                  // normalise in registers before this step's MFMAs
-        const int tapoff = ((tap / 3 - 1) * 18 + (tap - (tap / 3) * 3 - 1)) * LDS_ROW;
-        const float* Bb = Bs + buf * BN * LDS_ROW + (wn * TN * 32 + li) * LDS_ROW + kh * 4;
-#pragma unroll
-        for (int j = 0; j < KC / 8; ++j) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Hs + abase[i] + tapoff + j * 8);
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-                bf[i] = *reinterpret_cast<const float4*>(Bb + i * 32 * LDS_ROW + j * 8);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn) {
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[jn].x, acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[jn].y, acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[jn].z, acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[jn].w, acc[i][jn], 0, 0, 0);
-                }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < S_all) lstoreB(buf ^ 1);
-        __syncthreads();
-        if (tap == 8 && next_chunk) {                           // everyone is done with this chunk's halo
-            lstoreH();
-            __syncthreads();
-        }
+    // One K step with a literal TAP; the nine taps of a chunk are straight-line code and every load is unconditional
+    // (clamped at the tail), so hipcc's s_waitcnt bookkeeping stays exact: the weight tile of step s+1 and the halo of
+    // chunk c+1 (requested at tap 7, normalised in registers at tap 8, written after tap 8's barrier) stay in flight
+    // under the MFMAs instead of being drained by a conservative vmcnt(0) at a control-flow join.
+#define FLOWSE_STEP32(TAP)                                                                                           \
+    {                                                                                                                \
+        constexpr int tap = TAP;                                                                                     \
+        const int s = chunk * 9 + tap;                                                                               \
+        const int buf = s & 1;                                                                                       \
+        gloadB(min(s + 1, S_all - 1));                                                                               \
+        if (tap == 7) gloadH(min(chunk + 1, nchunks - 1));                                                           \
+        if (tap == 8) xformH();                                                                                      \
+        constexpr int tapoff = ((tap / 3 - 1) * 18 + (tap % 3 - 1)) * LDS_ROW;                                       \
+        const float* Bb = Bs + buf * BN * LDS_ROW + (wn * TN * 32 + li) * LDS_ROW + kh * 4;                          \
+        _Pragma("unroll") for (int j = 0; j < KC / 8; ++j) {                                                         \
+            float4 af[TM], bf[TN];                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                           \
+                af[i] = *reinterpret_cast<const float4*>(Hs + abase[i] + tapoff + j * 8);                            \
+            _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                           \
+                bf[i] = *reinterpret_cast<const float4*>(Bb + i * 32 * LDS_ROW + j * 8);                             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int jn = 0; jn < TN; ++jn) {       \
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[jn].x, acc[i][jn], 0, 0, 0);           \
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[jn].y, acc[i][jn], 0, 0, 0);           \
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[jn].z, acc[i][jn], 0, 0, 0);           \
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[jn].w, acc[i][jn], 0, 0, 0);           \
+            }                                                                                                        \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        lstoreB(buf ^ 1); /* at the very last step: a spare tile into the idle buffer */                             \
+        __syncthreads();                                                                                             \
+        if (tap == 8) { /* everyone is done with this chunk's halo */                                                \
+            lstoreH();                                                                                               \
+            __syncthreads();                                                                                         \
+        }                                                                                                            \
     }
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        FLOWSE_STEP32(0) FLOWSE_STEP32(1) FLOWSE_STEP32(2) FLOWSE_STEP32(3) FLOWSE_STEP32(4)
+        FLOWSE_STEP32(5) FLOWSE_STEP32(6) FLOWSE_STEP32(7) FLOWSE_STEP32(8)
+    }
+#undef FLOWSE_STEP32
     conv_epilogue<WM, WN, TM, TN>(a, acc, smem, m_tl, n0, M, HW, 0, W);
 }
 
