@@ -65,6 +65,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     constexpr int CROW = BN + 4;
     static_assert(BM * CROW <= 2 * (BM + BN) * LDS_ROW, "C tile must fit in the staging buffers");
     float* Cs = smem;                          // [BM][CROW]; safe: the last loop iteration ended with a barrier
+    constexpr int C4 = BN / 4;                 // float4 per tile row
+    constexpr int RPP = NT / C4;               // rows per pass
+    constexpr int NR = BM / RPP;               // rows per thread
+    const int ec4 = tid % C4, er0 = tid / C4;
+    const int n = n0 + ec4 * 4;
+    const bool ncol = n < a.Cout;              // Cout % 4 == 0: a quad is entirely inside or outside
+    const bool has_b2 = a.bias2 != nullptr && !a.partial, has_res = a.res != nullptr && !a.partial;
+    // Residual / per-sample bias quads of this thread's rows are requested FIRST (unconditional loads on clamped
+    // addresses), so they are in flight while the accumulators make their trip through LDS.
+    float4 rres[NR], rb2[NR];
+    if (has_res && ncol) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int rr = er0 + k * RPP;
+            const int m = rowW ? m0 + (rr >> 4) * rowW + (rr & 15) : m0 + rr;
+            rres[k] = *reinterpret_cast<const float4*>(a.res + (m < M ? (int64_t)m * a.Cout : 0) + n);
+        }
+    }
+    if (has_b2 && ncol) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int rr = er0 + k * RPP;
+            const int m = rowW ? m0 + (rr >> 4) * rowW + (rr & 15) : m0 + rr;
+            rb2[k] = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)(m < M ? m / HW : 0) * a.bias2_stride + n);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -75,12 +101,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                 Cs[row * CROW + (wn * TN + jn) * 32 + li] = acc[i][jn][r];
             }
     __syncthreads();
-    constexpr int C4 = BN / 4;                 // float4 per tile row
-    constexpr int RPP = NT / C4;               // rows per pass
-    const int ec4 = tid % C4, er0 = tid / C4;
-    const int n = n0 + ec4 * 4;
     if (a.partial) {                           // split-K slice: raw partial sums, epilogue in splitk_reduce
-        if (n < a.Cout) {
+        if (ncol) {
             float* dst = a.partial + (int64_t)split * M * a.Cout;
             for (int rr = er0; rr < BM; rr += RPP) {
                 const int m = rowW ? m0 + (rr >> 4) * rowW + (rr & 15) : m0 + rr;
@@ -91,29 +113,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         }
         return;
     }
-    if (n < a.Cout) {                          // Cout % 4 == 0: a quad is entirely inside or outside
+    if (ncol) {
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + n);
-        const bool has_b2 = a.bias2 != nullptr, has_res = a.res != nullptr;
         Stat4 st;
         st.init();
-#pragma unroll 4
-        for (int rr = er0; rr < BM; rr += RPP) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int rr = er0 + k * RPP;
             const int m = rowW ? m0 + (rr >> 4) * rowW + (rr & 15) : m0 + rr;
-            if (m >= M) break;
+            if (m >= M) continue;
             float4 v = *reinterpret_cast<const float4*>(Cs + rr * CROW + ec4 * 4);
             v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
-            if (has_b2) {
-                const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)(m / HW) * a.bias2_stride + n);
-                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
-            const int64_t o = (int64_t)m * a.Cout + n;
-            if (has_res) {
-                const float4 t = *reinterpret_cast<const float4*>(a.res + o);
-                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
+            if (has_b2) { v.x += rb2[k].x; v.y += rb2[k].y; v.z += rb2[k].z; v.w += rb2[k].w; }
+            if (has_res) { v.x += rres[k].x; v.y += rres[k].y; v.z += rres[k].z; v.w += rres[k].w; }
             v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
-            *reinterpret_cast<float4*>(a.out + o) = v;
+            *reinterpret_cast<float4*>(a.out + (int64_t)m * a.Cout + n) = v;
             st.add(v);
         }
         if (a.stats) {

@@ -637,7 +637,6 @@ struct Builder {
         const float rs2 = 0.70710678118654752440f;
         GnBuf g0 = gn(x1, x2, mod.w_gn0_g, mod.w_gn0_b);
         Tn h1, xs;
-        const int Cx = x1.C + (x2 ? x2->C : 0);
         if (!mod.up && !mod.down) {
             if (conv_supports_fused_gn(B, x1.H, x1.W, x1.C, x2 ? x2->C : 0, mod.out_ch, 9)) {
                 // Conv_0(act(GroupNorm_0(x))) in one kernel: the normalised tensor never reaches HBM
@@ -661,7 +660,6 @@ struct Builder {
             xs = conv("conv2_1x1", xr, nullptr, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f);
             release(xr);
         }
-        (void)Cx;
         GnBuf g1 = gn(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b);
         Tn out;
         if (conv_supports_fused_gn(B, h1.H, h1.W, h1.C, 0, mod.out_ch, 9)) {
