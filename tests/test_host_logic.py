@@ -208,3 +208,43 @@ def test_spec_transform_matches_reference_golden():
     assert Cs.rel_l2(Sf, g["fwd"]) < 1e-6
     assert Cs.rel_l2(st.spec_back(Sf), g["back"]) < 1e-5
     assert Cs.rel_l2(st.istft(st.spec_back(Sf), 4000), g["istft"]) < 1e-5
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under flowmse_amd/ (the product) may import or execute it."""
+    import ast
+    pkg = os.path.join(ROOT, "flowmse_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            path = os.path.join(dirpath, f)
+            tree = ast.parse(open(path).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                    offenders.append(path)
+    assert not offenders, offenders
+    for f in os.listdir(os.path.join(pkg, "csrc")):
+        assert "oracle" not in open(os.path.join(pkg, "csrc", f), errors="ignore").read()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """Without libflowse_hip.so the package refuses to import (no silent CPU / PyTorch fallback)."""
+    import subprocess
+    import sys
+    code = ("import importlib.util, sys, os\n"
+            "spec = importlib.util.spec_from_file_location('lib_copy', sys.argv[1])\n"
+            "m = importlib.util.module_from_spec(spec)\n"
+            "try:\n    spec.loader.exec_module(m)\nexcept ImportError as e:\n    print('IMPORTERROR', e); sys.exit(0)\n"
+            "sys.exit(1)\n")
+    src = open(os.path.join(ROOT, "flowmse_amd", "_lib.py")).read()
+    copy = tmp_path / "_lib_copy.py"
+    copy.write_text(src)                      # same module, but its directory holds no .so
+    r = subprocess.run([sys.executable, "-c", code, str(copy)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "IMPORTERROR" in r.stdout and "no CPU fallback" in r.stdout, r.stdout + r.stderr
