@@ -5,7 +5,7 @@
 //     w = softmax_j( sum_c q[b,c,i] k[b,c,j] * C^-1/2 );  h[b,c,i] = sum_j w[i,j] v[b,c,j]
 // q, k, v arrive token-major from one fused 1x1 projection: qkv[b][token][q(0:C) | k(C:2C) | v(2C:3C)].
 //
-// Flash-style, one 4-wave block per 32-query tile (the key tiles are dealt to the waves, whose online-softmax
+// Flash-style, one 8-wave block per 32-query tile (the key tiles are dealt to the waves, whose online-softmax
 // states are merged through LDS at the end), never materialising the L x L score matrix.  Both products are
 // computed TRANSPOSED so that every per-query quantity (running max, running sum, rescale factor) is
 // lane-local (lane & 31 = query):
@@ -20,7 +20,7 @@ namespace flowse {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int ATT_WAVES = 4;
+constexpr int ATT_WAVES = 8;     // key tiles are dealt to 8 waves (L = 256 -> one 32-key tile each)
 
 template <int NCT>   // C = 32 * NCT
 __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const float* __restrict__ qkv, int L,

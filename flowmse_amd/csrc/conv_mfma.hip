@@ -729,7 +729,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
 // Same reduction, organised like gn_stats (grid (HW / PB, B); a thread owns one channel quad and strides over the
 // block's PB pixels) so that it can also emit the GroupNorm partial sums of the tensor it writes:
 // stats[((b * nblk + blk) * Cout + c) * 2 + {0,1}].
-constexpr int SK_PB = 8;      // pixels per block (small: these tensors are tiny, parallelism matters)
+// pixels per block of the split-K reduction: small images want many blocks (parallelism), larger ones few
+// partials (every partial is later read by gn_finalize)
+static inline int sk_pixels_per_block(int HW) { return HW <= 8 ? HW : HW <= 1024 ? 8 : HW <= 4096 ? 32 : 64; }
 
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(ConvArgs a, int PB) {
     __shared__ float red[256 * 8];
@@ -793,7 +795,7 @@ int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps) {
     const int HW = H * W;
     if (Cout & 3) return 0;
     if (conv_ksplit(B, H, W, Cin, Cout, taps) != 1) {      // statistics come from the split-K reduction pass
-        const int PB = HW < SK_PB ? HW : SK_PB;
+        const int PB = sk_pixels_per_block(HW);
         return ((HW % PB) == 0 && Cout / 4 <= 256) ? HW / PB : 0;
     }
     return (HW % 128) == 0 ? HW / 128 : 0;
@@ -1179,7 +1181,7 @@ static int launch_halo_bf16(const ConvArgs& a, hipStream_t s) {
 int launch_splitk_reduce(const ConvArgs& a, hipStream_t s) {
     const int HW = a.H * a.W;
     if (a.stats) {
-        const int PB = HW < SK_PB ? HW : SK_PB;
+        const int PB = sk_pixels_per_block(HW);
         if (a.stats_nblk != HW / PB || (HW % PB) != 0 || a.Cout / 4 > 256) {
             set_error("splitk_reduce: inconsistent fused-stats geometry");
             return ERR_ARG;

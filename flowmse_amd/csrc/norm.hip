@@ -70,43 +70,55 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __res
     }
 }
 
-// grid (G, B), 64 threads.  Channels [0,C1) take their partials from set 1 (ppb1 pixels per block), [C1,C1+C2) from
+// grid (G, B), 256 threads.  Channels [0,C1) take their partials from set 1 (ppb1 pixels per block), [C1,C1+C2) from
 // set 2.  Blocks and channels are merged with Chan's formula in fp64: mean and biased variance of the group.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ p1, int nblk1, int ppb1, int C1,
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ p1, int nblk1, int ppb1, int C1,
                                                          const float* __restrict__ p2, int nblk2, int ppb2, int C2,
                                                          int HW, int G, const float* __restrict__ gamma, float eps,
                                                          float* __restrict__ mean, float* __restrict__ scale) {
-    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    __shared__ double wsum[4];
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;       // "lane" = thread 0..255 here
     const int C = C1 + C2;
     const int cpg = C / G;
-    double n = 0.0, mu = 0.0, m2 = 0.0;
+    // Two passes over the (block, channel) partials of the group, both plain fp64 sums (no divisions in the loops):
+    //   mean = sum n_i mean_i / N ;  var = sum (M2_i + n_i (mean_i - mean)^2) / N      (N = HW * cpg)
+    double s1 = 0.0;
     for (int j = 0; j < cpg; ++j) {
         const int c = g * cpg + j;
         const bool first = c < C1;
         const float* p = first ? p1 : p2;
         const int nblk = first ? nblk1 : nblk2, Cs = first ? C1 : C2, cc = first ? c : c - C1;
         const int ppb = first ? ppb1 : ppb2;
-        for (int blk = lane; blk < nblk; blk += 64) {
+        for (int blk = lane; blk < nblk; blk += 256)
+            s1 += (double)min(ppb, HW - blk * ppb) * (double)p[(((int64_t)b * nblk + blk) * Cs + cc) * 2];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o);
+    if ((lane & 63) == 0) wsum[lane >> 6] = s1;
+    __syncthreads();
+    s1 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const double N = (double)HW * cpg;
+    const double mu = s1 / N;
+    double s2 = 0.0;
+    for (int j = 0; j < cpg; ++j) {
+        const int c = g * cpg + j;
+        const bool first = c < C1;
+        const float* p = first ? p1 : p2;
+        const int nblk = first ? nblk1 : nblk2, Cs = first ? C1 : C2, cc = first ? c : c - C1;
+        const int ppb = first ? ppb1 : ppb2;
+        for (int blk = lane; blk < nblk; blk += 256) {
             const float* q = p + (((int64_t)b * nblk + blk) * Cs + cc) * 2;
-            const double nb = (double)min(ppb, HW - blk * ppb);
-            const double d = (double)q[0] - mu, nn = n + nb;
-            mu += d * nb / nn;
-            m2 += (double)q[1] + d * d * n * nb / nn;
-            n = nn;
+            const double d = (double)q[0] - mu;
+            s2 += (double)q[1] + (double)min(ppb, HW - blk * ppb) * d * d;
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double nb = __shfl_xor(n, o), mb = __shfl_xor(mu, o), qb = __shfl_xor(m2, o);
-        const double nn = n + nb;
-        if (nn > 0.0) {
-            const double d = mb - mu;
-            mu += d * nb / nn;
-            m2 += qb + d * d * n * nb / nn;
-            n = nn;
-        }
-    }
-    const double var = m2 / n;                      // n == HW * cpg
+    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+    if ((lane & 63) == 0) wsum[lane >> 6] = s2;
+    __syncthreads();
+    s2 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const double var = s2 / N;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float muf = (float)mu;
     if (lane < cpg) {
@@ -165,7 +177,7 @@ int launch_gn_finalize(const float* partial1, int nblk1, int C1, const float* pa
         set_error("gn_finalize: unsupported C=%d G=%d", C, G);
         return ERR_SHAPE;
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial1, nblk1, ppb1, C1, partial2, nblk2, ppb2,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, s, partial1, nblk1, ppb1, C1, partial2, nblk2, ppb2,
                        C2, HW, G, gamma, eps, mean, scale);
     FLOWSE_LAUNCH_CHECK();
     return OK;
