@@ -806,7 +806,7 @@ int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     const int64_t M = (int64_t)B * H * W;
     const int64_t tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
     const int steps = ((Cin + KC - 1) / KC) * taps;
-    if (tiles >= 256 || steps < 8) return 1;
+    if (tiles >= 256 || steps < 8) return 1;          // measured: 256 beats 128 and 64 at B = 1..8
     int64_t want = (512 + tiles - 1) / tiles;
     int64_t maxs = steps / 4;
     int64_t ks = want < maxs ? want : maxs;
@@ -1216,6 +1216,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
         }
         if (a.Cout <= 32) return launch_halo<4, 1, 1, 1>(a, s);
         if (a.Cout <= 64) return launch_halo<2, 2, 2, 1>(a, s);
+        // fewer than two 128x128 tiles per CU (single utterances): halve the N tile so that two blocks share every
+        // CU and cover each other's barriers / prologues
+        const int64_t tiles128 = ((int64_t)a.B * a.H * a.W / 128) * ((a.Cout + 127) / 128);
+        if (tiles128 < 512) return launch_halo<2, 2, 2, 1>(a, s);
         return launch_halo<2, 2, 2, 2>(a, s);
     }
     if (a.gn.mean) {
