@@ -478,6 +478,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
 // exactly once per block, the GroupNorm + SiLU of the consuming ResnetBlock (layerspp.py:246,265: Conv(act(GN(x))))
 // is applied right there, on the way into LDS -- the normalised tensor never exists in HBM.  Zero padding stays
 // exact: out-of-image halo pixels are written as 0 AFTER the activation.
+#ifndef FLOWSE_HTAP
+#define FLOWSE_HTAP 1
+#endif
 template <int WM, int WN, int TM, int TN, bool GN>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(ConvArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
@@ -550,23 +553,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(ConvArgs 
     };
     // GroupNorm + SiLU on the staged registers (VALU only; runs under the partner wave's MFMAs), then the plain
     // LDS write once every wave has left the previous chunk's halo.  v_exp / v_rcp based SiLU: ~2 ulp.
-    auto xformH = [&]() {
+    auto xform1 = [&](int q) {
         if (!GN) return;
-#pragma unroll
-        for (int q = 0; q < H_LOADS; ++q) {
-            const bool in = (hin >> q) & 1u;
-            float4 v;
-            v.x = __uint_as_float(rh[q].x); v.y = __uint_as_float(rh[q].y);
-            v.z = __uint_as_float(rh[q].z); v.w = __uint_as_float(rh[q].w);
-            v.x = fmaf(v.x - g_mu.x, g_sc.x, g_be.x); v.y = fmaf(v.y - g_mu.y, g_sc.y, g_be.y);
-            v.z = fmaf(v.z - g_mu.z, g_sc.z, g_be.z); v.w = fmaf(v.w - g_mu.w, g_sc.w, g_be.w);
-            if (a.gn_silu) {
-                v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
-                v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
-            }
-            rh[q].x = in ? __float_as_uint(v.x) : 0u; rh[q].y = in ? __float_as_uint(v.y) : 0u;
-            rh[q].z = in ? __float_as_uint(v.z) : 0u; rh[q].w = in ? __float_as_uint(v.w) : 0u;
+        const bool in = (hin >> q) & 1u;
+        float4 v;
+        v.x = __uint_as_float(rh[q].x); v.y = __uint_as_float(rh[q].y);
+        v.z = __uint_as_float(rh[q].z); v.w = __uint_as_float(rh[q].w);
+        v.x = fmaf(v.x - g_mu.x, g_sc.x, g_be.x); v.y = fmaf(v.y - g_mu.y, g_sc.y, g_be.y);
+        v.z = fmaf(v.z - g_mu.z, g_sc.z, g_be.z); v.w = fmaf(v.w - g_mu.w, g_sc.w, g_be.w);
+        if (a.gn_silu) {
+            v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
+            v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
         }
+        rh[q].x = in ? __float_as_uint(v.x) : 0u; rh[q].y = in ? __float_as_uint(v.y) : 0u;
+        rh[q].z = in ? __float_as_uint(v.z) : 0u; rh[q].w = in ? __float_as_uint(v.w) : 0u;
+    };
+    auto xformH = [&]() {
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) xform1(q);
     };
     auto lstoreH = [&]() {
 #pragma unroll
@@ -611,6 +615,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(ConvArgs 
 
     const int nchunks = Cin / KC;
     const int S_all = nchunks * 9;
+    constexpr int HTAP = GN ? FLOWSE_HTAP : 7;           // tap at which the next chunk's halo is requested
 
     gloadH(0);
     gloadB(0);
@@ -629,8 +634,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(ConvArgs 
         const int s = chunk * 9 + tap;                                                                               \
         const int buf = s & 1;                                                                                       \
         gloadB(min(s + 1, S_all - 1));                                                                               \
-        if (tap == 7) gloadH(min(chunk + 1, nchunks - 1));                                                           \
-        if (tap == 8) xformH();                                                                                      \
+        if (tap == HTAP) gloadH(min(chunk + 1, nchunks - 1));                                                        \
+        if (HTAP == 7 && tap == 8) xformH();                                                                         \
+        if (HTAP < 7 && tap > HTAP && tap - HTAP - 1 < H_LOADS) xform1(tap - HTAP - 1);                              \
         constexpr int tapoff = ((tap / 3 - 1) * 18 + (tap % 3 - 1)) * LDS_ROW;                                       \
         const float* Bb = Bs + buf * BN * LDS_ROW + (wn * TN * 32 + li) * LDS_ROW + kh * 4;                          \
         _Pragma("unroll") for (int j = 0; j < KC / 8; ++j) {                                                         \
