@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from flowmse_amd.sampling import get_white_box_solver
-from flowmse_amd.util.other import pad_spec
+from flowmse_amd.util.other import pad_spec, read_wav as _read_wav
 
 
 def energy_ratios(s_hat, s, n):
@@ -74,16 +74,6 @@ def enhance_batch(model, ys, N=5, T_rev=1.0, t_eps=0.03, odesolver="euler"):
     sample, _ = get_white_box_solver(odesolver, model.ode, model, Y=Y, Y_prior=Y, T_rev=T_rev, t_eps=t_eps, N=N)()
     return [(model.to_audio(sample[i, 0], y.size(1)) * n).squeeze().cpu().numpy()
             for i, (y, n) in enumerate(zip(ys, norms))]
-
-
-def _read_wav(path):
-    from scipy.io import wavfile
-    sr, data = wavfile.read(path)
-    if data.dtype.kind == "i":
-        data = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
-    if data.ndim > 1:
-        data = data[:, 0]
-    return torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))[None], sr
 
 
 def _write_wav(path, x, sr=16000):

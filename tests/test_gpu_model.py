@@ -269,6 +269,27 @@ def test_end_to_end_utterance_vs_oracle(full, tmp_path):
     assert os.path.exists(out + "/_results.csv") and os.path.exists(out + "/_settings.txt")
 
 
+def test_evaluate_model_hook_gpu(full, tmp_path):
+    """Validation hook (util/inference.py:15-71) on the HIP model: deterministic under a fixed seed, finite SI-SDR,
+    and equal to scoring enhance_waveform by hand on the same picks."""
+    from test_host_logic import _valid_set
+    from flowmse_amd.evaluate import enhance_waveform
+    from flowmse_amd.util.inference import evaluate_model
+    from flowmse_amd.util.other import read_wav, si_sdr
+    full.data_module.valid_set = vs = _valid_set(tmp_path, 3)
+    try:
+        torch.manual_seed(5)
+        _, s1, _ = evaluate_model(full, 2, inference_N=2)
+        torch.manual_seed(5)
+        want = 0.0
+        for i in (0, 2):
+            y = read_wav(vs.noisy_files[i])[0].cuda()
+            want += si_sdr(read_wav(vs.clean_files[i])[0][0].numpy(), enhance_waveform(full, y, N=2)) / 2
+    finally:
+        del full.data_module.valid_set
+    assert np.isfinite(s1) and abs(s1 - want) < 1e-3, (s1, want)
+
+
 def test_enhance_sharded_ragged_matches_per_utterance(tiny):
     """Config-4 driver on one rank: ragged utterances batched by padded length == one-at-a-time enhancement."""
     from flowmse_amd.parallel import enhance_sharded

@@ -195,6 +195,37 @@ def test_config0_cpu_plumbing_with_oracle_field():
     assert all(np.isfinite(v) for v in r)
 
 
+def _valid_set(tmp_path, n, seconds=1.0):
+    """n clean/noisy wav pairs on disk + the data_module.valid_set view evaluate_model reads."""
+    import types
+    from scipy.io import wavfile
+    from flowmse_amd.evaluate import _synthetic_pairs
+    clean, noisy = [], []
+    for name, c, y in _synthetic_pairs(n, seconds=seconds):
+        for kind, sig, lst in (("clean", c, clean), ("noisy", y, noisy)):
+            path = str(tmp_path / f"{kind}_{name}")
+            wavfile.write(path, 16000, sig)
+            lst.append(path)
+    return types.SimpleNamespace(clean_files=clean, noisy_files=noisy)
+
+
+def test_evaluate_model_hook_cpu(tmp_path):
+    """util/inference.py:15-71 contract: picks files uniformly, returns (pesq, si_sdr, estoi) means; with a zero
+    vector field and sigma -> 0 the 'enhanced' signal is the noisy one, so SI-SDR equals the mixture's."""
+    from flowmse_amd.model import VFModel
+    from flowmse_amd.util.inference import evaluate_model
+    from flowmse_amd.util.other import read_wav, si_sdr
+    host = VFModel(nf=8, ch_mult=(1, 1, 1, 1, 1, 1, 1), num_res_blocks=1, image_size=256, sigma_min=0.0, sigma_max=1e-6)
+    host.data_module.valid_set = _valid_set(tmp_path, 4)
+    p, s, e = evaluate_model(host, 2, inference_N=3, VF_fn=lambda x, t, y: torch.zeros_like(x))
+    vs = host.data_module.valid_set
+    want = np.mean([si_sdr(read_wav(vs.clean_files[i])[0][0].numpy(), read_wav(vs.noisy_files[i])[0][0].numpy())
+                    for i in (0, 3)])
+    assert abs(s - want) < 0.05, (s, want)
+    assert np.isnan(p) or np.isfinite(p)
+    assert np.isnan(e) or np.isfinite(e)
+
+
 def test_spec_transform_matches_reference_golden():
     """STFT / spec_fwd / spec_back / iSTFT against the reference's SpecsDataModule (tests/golden/op_spec.npz)."""
     from flowmse_amd.data_module import SpecTransform
