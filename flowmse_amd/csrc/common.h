@@ -115,7 +115,14 @@ struct ConvArgs {
     const void* wq = nullptr;
     int terms = 0;
     int wq_f16 = 0;     // 1: the planes hold IEEE half instead of bf16 (terms must be 1; BASELINE config 5)
+    // optional F(2,3) Winograd weights of a 3x3 conv, [Cout][kx = 3][component = 4][Cin] (launch_wino_weights):
+    // when set and the shape qualifies (conv_supports_wino) the fp32 halo kernel runs its Winograd variant
+    const float* wino = nullptr;
 };
+// F(2,3) weight transform along the kernel's vertical axis: packed [Cout][9][Cin] -> [Cout][3][4][Cin], on device
+int launch_wino_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s);
+inline int64_t conv_wino_numel(int Cout, int Cin) { return (int64_t)Cout * 12 * Cin; }
+bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // host helper: split fp32 conv weights [Cout][Cin][3][3] into the packed bf16 planes described above
 void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst, bool f16 = false);
 inline int64_t conv_bf16_numel(int Cout, int Cin, int terms) { return (int64_t)Cout * 9 * Cin * (terms == 1 ? 1 : 2); }

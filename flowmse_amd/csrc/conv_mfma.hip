@@ -858,6 +858,253 @@ static int launch_halo(const ConvArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// F(2,3) Winograd variant of the LDS-halo 3x3 kernel (fp32, the production kernel when Cout % 64 == 0).
+//
+// The 3x3 filter is factored along its VERTICAL axis: a pair of vertically adjacent output pixels (y, y+1) needs
+// the four input rows d0..d3 = y-1..y+2 and, per horizontal tap kx, the four products
+//     m0 = (d0 - d2) g0,  m1 = (d1 + d2) (g0+g1+g2)/2,  m2 = (d2 - d1) (g0-g1+g2)/2,  m3 = (d1 - d3) g2
+//     out(y) = m0 + m1 + m2,   out(y+1) = m1 - m2 - m3                      (g_k = w[ky = k][kx])
+// i.e. 4 multiplies where the direct form spends 6: the matrix cores execute 2/3 of the direct-convolution FLOPs.
+// The block still owns an 8 x 16 pixel tile = 64 row pairs (4 x 16) and BN = 64 output channels; the GEMM rows are
+// the PAIRS, each wave accumulates the four components of a 32-pair x 32-channel tile (4 x 16 accumulators) and
+// combines them once, in registers, before the shared epilogue.  The input transform costs four VALU subtractions
+// per float4 fragment, taken from the same LDS halo tile the direct kernel stages (GroupNorm + SiLU fused in the
+// same way); the weights are pre-transformed (launch_wino_weights, [Cout][kx][component][Cin]).  One K step =
+// (32-channel chunk, kx): 4 components x 64 channels x 32 weights = one 36 KB LDS tile, single-buffered
+// (registers hold the next one), which keeps two blocks per CU.
+template <bool GN>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
+    constexpr int BN = 64, NT = 256;
+    constexpr int HROWS = 180;                           // 10 x 18 halo pixels
+    constexpr int H_LOADS = 6;
+    constexpr int BROWS = 4 * BN;                        // weight rows per step: [component][channel]
+    constexpr int B_LOADS = BROWS * 8 / NT;              // 8 float4 per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                                    // [HROWS][LDS_ROW]
+    float* Bs = smem + HROWS * LDS_ROW;                  // [BROWS][LDS_ROW]
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int M = a.B * HW;
+    const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
+    const int n_ntiles = a.Cout / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
+    const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 3);
+    const int b = mt / tiles_img, tt = mt - b * tiles_img;
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int y0 = ty * 8, x0 = tx * 16, n0 = nt * BN;
+    const int m_tl = (b * H + y0) * W + x0;
+
+    const int col4 = tid & 7, row0 = tid >> 3;
+    unsigned hvo1[H_LOADS], hvo2[H_LOADS];
+    unsigned hin = 0;
+#pragma unroll
+    for (int q = 0; q < H_LOADS; ++q) {
+        const int hr = row0 + 32 * q;
+        const int hy = hr / 18, hx = hr - hy * 18;
+        const bool in = hr < HROWS && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+        hvo1[q] = in ? (unsigned)((hy * W + hx) * C1 + col4 * 4) * 4u : OOB;
+        hvo2[q] = in ? (unsigned)((hy * W + hx) * C2 + col4 * 4) * 4u : OOB;
+        hin |= in ? (1u << q) : 0u;
+    }
+    unsigned bvo[B_LOADS];                               // weight row r = row0 + 32q: component r / 64, channel r % 64
+#pragma unroll
+    for (int q = 0; q < B_LOADS; ++q) {
+        const int r = row0 + 32 * q;
+        const int n = n0 + (r & 63);
+        bvo[q] = (unsigned)((n * 12 + (r >> 6)) * Cin + col4 * 4) * 4u;
+    }
+    const int64_t wbase = (int64_t)m_tl - W - 1;
+    const int wpix = 9 * W + 18;
+    const __amdgpu_buffer_rsrc_t rsrc1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1 + wbase * C1), 0, wpix * C1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(C2 ? a.in2 + wbase * C2 : a.in1), 0, C2 ? wpix * C2 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wino), 0, a.Cout * 12 * Cin * 4, 0x00020000);
+
+    u32x4 rh[H_LOADS], rb[B_LOADS];
+    float4 g_mu, g_sc, g_be;
+
+    auto gloadH = [&](int chunk) {
+        const int c0 = chunk * KC;
+        const bool second = c0 >= C1;
+        const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * 4u;
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q)
+            rh[q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, hvo2[q], soff, 0)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, hvo1[q], soff, 0);
+        if (GN) {
+            const int cg = c0 + col4 * 4;
+            g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
+            g_sc = *reinterpret_cast<const float4*>(a.gn.scale + (int64_t)b * Cin + cg);
+            g_be = *reinterpret_cast<const float4*>(a.gn.beta + cg);
+        }
+    };
+    auto xform1 = [&](int q) {
+        if (!GN) return;
+        const bool in = (hin >> q) & 1u;
+        float4 v;
+        v.x = __uint_as_float(rh[q].x); v.y = __uint_as_float(rh[q].y);
+        v.z = __uint_as_float(rh[q].z); v.w = __uint_as_float(rh[q].w);
+        v.x = fmaf(v.x - g_mu.x, g_sc.x, g_be.x); v.y = fmaf(v.y - g_mu.y, g_sc.y, g_be.y);
+        v.z = fmaf(v.z - g_mu.z, g_sc.z, g_be.z); v.w = fmaf(v.w - g_mu.w, g_sc.w, g_be.w);
+        if (a.gn_silu) {
+            v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
+            v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
+        }
+        rh[q].x = in ? __float_as_uint(v.x) : 0u; rh[q].y = in ? __float_as_uint(v.y) : 0u;
+        rh[q].z = in ? __float_as_uint(v.z) : 0u; rh[q].w = in ? __float_as_uint(v.w) : 0u;
+    };
+    auto lstoreH = [&]() {
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            const int hr = row0 + 32 * q;
+            if (hr < HROWS) *reinterpret_cast<u32x4*>(Hs + hr * LDS_ROW + col4 * 4) = rh[q];
+        }
+    };
+    auto gloadB = [&](int s) {                           // step s = chunk * 3 + kx
+        const int chunk = s / 3, kx = s - chunk * 3;
+        const unsigned soff_b = (unsigned)(kx * 4 * Cin + chunk * KC) * 4u;
+#pragma unroll
+        for (int q = 0; q < B_LOADS; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo[q], soff_b, 0);
+    };
+    auto lstoreB = [&]() {
+#pragma unroll
+        for (int q = 0; q < B_LOADS; ++q)
+            *reinterpret_cast<u32x4*>(Bs + (row0 + 32 * q) * LDS_ROW + col4 * 4) = rb[q];
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, kh = lane >> 5;
+    // this lane's pair: tile row pair 2*wm + (li >> 4), column li & 15; its four input rows start at halo row 2*pair
+    const int abase = ((2 * (2 * wm + (li >> 4))) * 18 + (li & 15)) * LDS_ROW + kh * 4;
+    const float* Bw = Bs + (wn * 32 + li) * LDS_ROW + kh * 4;
+
+    f32x16 acc[4];                                       // the four Winograd components
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    const int nchunks = Cin / KC;
+    const int S_all = nchunks * 3;
+
+    gloadH(0);
+    gloadB(0);
+#pragma unroll
+    for (int q = 0; q < H_LOADS; ++q) xform1(q);
+    lstoreH();
+    lstoreB();
+    __syncthreads();
+
+#define FLOWSE_WSTEP(KX)                                                                                             \
+    {                                                                                                                \
+        constexpr int kx = KX;                                                                                       \
+        const int s = chunk * 3 + kx;                                                                                \
+        gloadB(min(s + 1, S_all - 1));                                                                               \
+        if (kx == 0) gloadH(min(chunk + 1, nchunks - 1));                                                            \
+        if (kx == 1) { xform1(0); xform1(1); xform1(2); }                                                            \
+        if (kx == 2) { xform1(3); xform1(4); xform1(5); }                                                            \
+        _Pragma("unroll") for (int j = 0; j < KC / 8; ++j) {                                                         \
+            const float* Ha = Hs + abase + kx * LDS_ROW + j * 8;                                                     \
+            const float4 d0 = *reinterpret_cast<const float4*>(Ha);                                                  \
+            const float4 d1 = *reinterpret_cast<const float4*>(Ha + 18 * LDS_ROW);                                   \
+            const float4 d2 = *reinterpret_cast<const float4*>(Ha + 36 * LDS_ROW);                                   \
+            const float4 d3 = *reinterpret_cast<const float4*>(Ha + 54 * LDS_ROW);                                   \
+            float4 bf[4], v[4];                                                                                      \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                            \
+                bf[c] = *reinterpret_cast<const float4*>(Bw + c * BN * LDS_ROW + j * 8);                             \
+            v[0] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);                                  \
+            v[1] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);                                  \
+            v[2] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);                                  \
+            v[3] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);                                  \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].x, bf[c].x, acc[c], 0, 0, 0);                     \
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].y, bf[c].y, acc[c], 0, 0, 0);                     \
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].z, bf[c].z, acc[c], 0, 0, 0);                     \
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].w, bf[c].w, acc[c], 0, 0, 0);                     \
+            }                                                                                                        \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __syncthreads(); /* every wave has left this step's weight tile (and, at kx = 2, the chunk's halo) */        \
+        lstoreB();                                                                                                   \
+        if (kx == 2) lstoreH();                                                                                      \
+        __syncthreads();                                                                                             \
+    }
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        FLOWSE_WSTEP(0) FLOWSE_WSTEP(1) FLOWSE_WSTEP(2)
+    }
+#undef FLOWSE_WSTEP
+
+    // output transform in registers; accumulator register r of a 32x32 tile holds pair row (r&3) + 8*(r>>2) + 4*kh:
+    // registers 0-7 belong to the wave's first row pair, 8-15 to the second, which is exactly the split the direct
+    // kernel's <2,2,2,1> epilogue expects between its two 32-pixel tiles (two image rows x 16 columns each)
+    f32x16 outp[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 8 * i + q;
+            outp[i][0][q] = acc[0][r] + acc[1][r] + acc[2][r];
+            outp[i][0][q + 8] = acc[1][r] - acc[2][r] - acc[3][r];
+        }
+    conv_epilogue<2, 2, 2, 1>(a, outp, smem, m_tl, n0, M, HW, 0, W);
+}
+
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                           float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (n, kx, ci)
+    if (idx >= (int64_t)Cout * 3 * Cin) return;
+    const int ci = (int)(idx % Cin);
+    const int kx = (int)((idx / Cin) % 3);
+    const int64_t n = idx / ((int64_t)3 * Cin);
+    const float g0 = w[(n * 9 + 0 + kx) * Cin + ci], g1 = w[(n * 9 + 3 + kx) * Cin + ci],
+                g2 = w[(n * 9 + 6 + kx) * Cin + ci];
+    float* o = out + ((n * 3 + kx) * 4) * Cin + ci;
+    o[0] = g0;
+    o[(int64_t)Cin] = 0.5f * ((g0 + g2) + g1);
+    o[(int64_t)2 * Cin] = 0.5f * ((g0 + g2) - g1);
+    o[(int64_t)3 * Cin] = g2;
+}
+
+int launch_wino_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s) {
+    const int64_t n = (int64_t)Cout * 3 * Cin;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w_packed, Cout, Cin, out);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+static const bool g_no_wino = getenv("FLOWSE_NO_WINOGRAD") != nullptr;
+
+bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps) {
+    return !g_no_wino && (Cout % 64) == 0 && conv_supports_fused_gn(B, H, W, C1, C2, Cout, taps) &&
+           (int64_t)Cout * 12 * (C1 + C2) * 4 < (1LL << 31);
+}
+
+static int launch_wino(const ConvArgs& a, hipStream_t s) {
+    const int64_t M = (int64_t)a.B * a.H * a.W;
+    const int grid = (int)(M / 128) * (a.Cout / 64);
+    const size_t lds = (180 + 256) * LDS_ROW * sizeof(float);          // > the <2,2,2,1> epilogue's 43 KB
+    static bool attr_done = false;
+    if (!attr_done) {
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    if (a.gn.mean)
+        hipLaunchKernelGGL(conv3x3_wino_kernel<true>, dim3(grid), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(conv3x3_wino_kernel<false>, dim3(grid), dim3(256), lds, s, a);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // bf16 matrix-core variant of the LDS-halo 3x3 kernel (optional precision modes, off by default).
 //
 // Same tiling and data flow as conv3x3_halo_kernel; the operands are bf16 for v_mfma_f32_32x32x16_bf16 (16x the
@@ -1220,6 +1467,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
             set_error("conv: 16-bit path needs terms = 1 (bf16 / f16) or 3 (bf16 only)");
             return ERR_ARG;
         }
+        if (a.wino && conv_supports_wino(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) return launch_wino(a, s);
         if (a.Cout <= 32) return launch_halo<4, 1, 1, 1>(a, s);
         if (a.Cout <= 64) return launch_halo<2, 2, 2, 1>(a, s);
         // fewer than two 128x128 tiles per CU (single utterances): halve the N tile so that two blocks share every

@@ -157,6 +157,9 @@ struct flowse_model {
     int precision = 0;                     // 0 fp32 (exact), 1 bf16x3 split (fp32-class), 2 bf16, 3 fp16 operands
     uint16_t* d_wq = nullptr;              // bf16 planes of the 3x3 ResBlock convs (precision != 0)
     int64_t d_wq_numel = 0;
+    float* d_wino = nullptr;               // F(2,3) Winograd weights of the 3x3 convs the halo kernel can take
+    int64_t d_wino_numel = 0;
+    std::map<int64_t, int64_t> wino_of;    // packed weight offset (d_w) -> offset in d_wino
     char* d_ws = nullptr;                  // activation workspace
     size_t d_ws_bytes = 0;
     float* d_ts = nullptr;                 // [N][B] solver times
@@ -341,6 +344,8 @@ static int build_structure(flowse_model* m) {
 // ------------------------------------------------------------------------------------------- weight packing
 struct Packer {
     std::vector<float> host;
+    struct WinoReq { int64_t off; int Cout, Cin; };
+    std::vector<WinoReq> wino;             // 3x3 convs that also get F(2,3) weights (transformed on the device)
     int64_t put(int64_t n) {
         const int64_t off = ((int64_t)host.size() + 63) & ~(int64_t)63;
         host.resize(off + n, 0.f);
@@ -356,6 +361,7 @@ static int64_t pack_conv(Packer& pk, const float* src, int Cout, int Cin, int ta
         for (int ci = 0; ci < Cin; ++ci)
             for (int t = 0; t < taps; ++t)
                 dst[((int64_t)co * taps + t) * Cin + ci] = src[((int64_t)co * Cin + ci) * taps + t];
+    if (taps == 9 && (Cin % 32) == 0 && (Cout % 64) == 0) pk.wino.push_back({off, Cout, Cin});
     return off;
 }
 static int64_t pack_copy(Packer& pk, const float* src, int64_t n) {
@@ -564,6 +570,9 @@ struct Builder {
         const bool use_bf16 = wq_off >= 0 && M->precision != 0 && taps == 9 &&
                               conv_supports_bf16(Bn, H, Wd, C1, C2, Cout, taps);
         const int terms = M->precision == 1 ? 3 : 1;
+        const auto wino_it = M->wino_of.find(w);
+        const int64_t wino_off = (taps == 9 && !cin4 && wino_it != M->wino_of.end() &&
+                                  conv_supports_wino(Bn, H, Wd, C1, C2, Cout, taps)) ? wino_it->second : -1;
         const size_t part_off = ks > 1 ? arena.alloc((size_t)ks * Bn * H * Wd * Cout * sizeof(float)) : 0;
         const size_t table_off = M_table_off;     // by value: the Builder dies before the plan runs
         const std::string full_label = label + "@" + std::to_string(H) + "x" + std::to_string(Wd) + ":" +
@@ -596,6 +605,7 @@ struct Builder {
                 c.terms = terms;
                 c.wq_f16 = M->precision == 3 ? 1 : 0;
             }
+            if (wino_off >= 0) c.wino = M->d_wino + wino_off;
             return c;
         };
         const double flops = 2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2);
@@ -945,6 +955,7 @@ void flowse_model_destroy(flowse_model* m) {
     if (m->d_ws) (void)hipFree(m->d_ws);
     if (m->d_ts) (void)hipFree(m->d_ts);
     if (m->d_wq) (void)hipFree(m->d_wq);
+    if (m->d_wino) (void)hipFree(m->d_wino);
     for (hipEvent_t e : m->prof_pool) (void)hipEventDestroy(e);
     delete m;
 }
@@ -1012,6 +1023,26 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
         m->d_w_numel = (int64_t)pk.host.size();
     }
     FLOWSE_HIP(hipMemcpy(m->d_w, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    // F(2,3) Winograd weights, derived on the device from the packed fp32 weights just uploaded
+    m->wino_of.clear();
+    int64_t wino_total = 0;
+    for (auto& r : pk.wino) {
+        m->wino_of[r.off] = wino_total;
+        wino_total += (conv_wino_numel(r.Cout, r.Cin) + 63) & ~(int64_t)63;
+    }
+    if (m->d_wino && m->d_wino_numel < wino_total) {
+        FLOWSE_HIP(hipFree(m->d_wino));
+        m->d_wino = nullptr;
+    }
+    if (!m->d_wino && wino_total > 0) {
+        FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_wino), wino_total * sizeof(float)));
+        m->d_wino_numel = wino_total;
+    }
+    for (auto& r : pk.wino) {
+        const int wrc = launch_wino_weights(m->d_w + r.off, r.Cout, r.Cin, m->d_wino + m->wino_of[r.off], nullptr);
+        if (wrc != OK) return wrc;
+    }
+    FLOWSE_HIP(hipDeviceSynchronize());
     // optional bf16 planes for the 3x3 ResBlock convolutions the halo kernel can take
     for (auto& mod : m->mods) mod.wq_c0 = mod.wq_c1 = -1;
     if (m->precision != 0) {
@@ -1287,6 +1318,50 @@ int flowse_op_conv3x3_gn(const float* in1, int C1, const float* in2, int C2, con
     c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = 9; c.scale = scale;
     c.gn = GnParams{mean, scl, beta};
     c.gn_silu = silu;
+    return launch_conv(c, s);
+}
+
+int64_t flowse_op_conv3x3_f23_scratch_floats(int B, int H, int W, int C, int Cout) {
+    return flowse_op_group_norm_scratch_floats(B, H * W, C) + conv_wino_numel(Cout, C);
+}
+
+int flowse_op_conv3x3_f23(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
+                          float eps, int silu, const float* w, const float* bias, const float* bias2, int bias2_stride,
+                          const float* res, float* out, int B, int H, int W, int Cout, float scale, float* scratch,
+                          void* stream) {
+    if (!in1 || !w || !out || !scratch || (gamma && !beta)) {
+        set_error("flowse_op_conv3x3_f23: null argument");
+        return ERR_ARG;
+    }
+    if (!in2) C2 = 0;
+    if (!conv_supports_wino(B, H, W, C1, C2, Cout, 9)) {
+        set_error("flowse_op_conv3x3_f23: shape B=%d H=%d W=%d C=%d+%d Cout=%d not covered by the Winograd kernel", B,
+                  H, W, C1, C2, Cout);
+        return ERR_SHAPE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int C = C1 + C2, HW = H * W;
+    float* wf = scratch + flowse_op_group_norm_scratch_floats(B, HW, C);
+    int rc = launch_wino_weights(w, Cout, C, wf, s);
+    if (rc != OK) return rc;
+    ConvArgs c;
+    c.in1 = in1; c.in2 = in2; c.C1 = C1; c.C2 = C2;
+    c.w = w; c.bias = bias; c.bias2 = bias2; c.bias2_stride = bias2_stride; c.res = res; c.out = out;
+    c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = 9; c.scale = scale;
+    c.wino = wf;
+    if (gamma) {
+        const int G = std::min(C / 4, 32);
+        const int nblk = gn_partial_blocks(HW, C);
+        float* part = scratch;
+        float* mean = scratch + (int64_t)B * nblk * C * 2;
+        float* scl = mean + (int64_t)B * C;
+        rc = launch_gn_stats(in1, C1, in2, C2, B, HW, part, nblk, s);
+        if (rc != OK) return rc;
+        rc = launch_gn_finalize(part, nblk, C, nullptr, 0, 0, B, HW, G, gamma, eps, mean, scl, s);
+        if (rc != OK) return rc;
+        c.gn = GnParams{mean, scl, beta};
+        c.gn_silu = silu;
+    }
     return launch_conv(c, s);
 }
 

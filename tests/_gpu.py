@@ -126,6 +126,30 @@ def conv3x3_gn(x1, gamma, beta, w, bias=None, x2=None, bias2=None, res=None, sca
     return nchw(out)
 
 
+def conv3x3_f23(x1, w, gamma=None, beta=None, bias=None, x2=None, bias2=None, res=None, scale=1.0, silu=True,
+                eps=1e-6):
+    """Same contract as conv3x3_gn (gamma None: no normalisation) through the F(2,3) Winograd halo kernel."""
+    Cout, Cin, k, _ = w.shape
+    a1 = nhwc(x1)
+    a2 = nhwc(x2) if x2 is not None else None
+    B, H, W, C1 = a1.shape
+    C2 = a2.shape[3] if a2 is not None else 0
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous().cuda()
+    bb = bias.contiguous().cuda() if bias is not None else None
+    b2 = bias2.contiguous().cuda() if bias2 is not None else None
+    rr = nhwc(res) if res is not None else None
+    g = gamma.cuda().contiguous() if gamma is not None else None
+    be = beta.cuda().contiguous() if beta is not None else None
+    scratch = torch.empty(L.flowse_op_conv3x3_f23_scratch_floats(B, H, W, C1 + C2, Cout), device="cuda")
+    out = torch.empty(B, H, W, Cout, device="cuda")
+    _lib.check(L.flowse_op_conv3x3_f23(_lib.ptr(a1), C1, _lib.ptr(a2), C2, _lib.ptr(g), _lib.ptr(be), eps, int(silu),
+                                       _lib.ptr(wp), _lib.ptr(bb), _lib.ptr(b2),
+                                       b2.shape[1] if b2 is not None else 0, _lib.ptr(rr), _lib.ptr(out), B, H, W, Cout,
+                                       float(scale), _lib.ptr(scratch), stream()))
+    torch.cuda.synchronize()
+    return nchw(out)
+
+
 def stft_compress(sig, scale=1.0, factor=0.15, exponent=0.5, pad_multiple=64):
     B, Ls = sig.shape
     T = Ls // 128 + 1

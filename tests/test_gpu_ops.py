@@ -135,6 +135,54 @@ def test_conv3x3_halo_fused_gn(G, case):
     assert C.rel_l2(plain, ref) < TOL
 
 
+WINO_CASES = [
+    # B, H, W, C1, C2, Cout, bias2, res, scale, silu
+    (2, 128, 128, 128, 0, 128, True, True, 0.70710678, True),
+    (2, 256, 64, 256, 128, 128, True, False, 1.0, True),
+    (4, 64, 64, 128, 128, 256, False, True, 1.0, True),
+    (1, 128, 144, 32, 0, 192, False, False, 1.0, False),      # W = 9 tiles, three 64-wide N tiles
+    (1, 256, 128, 64, 0, 64, False, True, 1.0, True),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv3x3_winograd_f23(G, case):
+    """F(2,3) Winograd form of the halo kernel (with and without the fused GroupNorm + SiLU input stage) against
+    the plain fp32 direct convolution; also against the direct HIP kernel on the same input."""
+    B, H, W, C1, C2, Cout, has_b2, has_res, scale, silu = case
+    Cc = C1 + C2
+    x1 = rnd(41, (B, C1, H, W)) * 1.5 + 0.3
+    x2 = rnd(42, (B, C2, H, W)) * 0.7 - 0.2 if C2 else None
+    g = 1.0 + rnd(43, (Cc,), 0.2)
+    be = rnd(44, (Cc,), 0.2)
+    w = rnd(45, (Cout, Cc, 3, 3), (1.0 / (Cc * 9)) ** 0.5)
+    bias = rnd(46, (Cout,), 0.1)
+    bias2 = rnd(47, (B, Cout + 4), 0.1) if has_b2 else None
+    res = rnd(48, (B, Cout, H, W)) if has_res else None
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    hn = F.group_norm(xin, min(Cc // 4, 32), g, be, eps=1e-6)
+    if silu:
+        hn = F.silu(hn)
+
+    def finish(t):
+        if has_b2:
+            t = t + bias2[:, :Cout, None, None]
+        if has_res:
+            t = t + res
+        return t * scale
+
+    ref = finish(F.conv2d(hn.double(), w.double(), bias.double(), padding=1).float())
+    got = G.conv3x3_f23(x1, w, g, be, bias, x2, bias2, res, scale, silu)
+    err = C.rel_l2(got, ref)
+    direct = C.rel_l2(G.conv3x3_gn(x1, g, be, w, bias, x2, bias2, res, scale, silu), ref)
+    print(f"winograd rel-L2 {err:.2e}   direct kernel {direct:.2e}")
+    assert err < TOL
+    # plain conv (no normalisation), unnormalised input with a DC offset: the row differences d0 - d2 cancel it
+    ref0 = finish(F.conv2d(xin.double(), w.double(), bias.double(), padding=1).float())
+    got0 = G.conv3x3_f23(x1, w, None, None, bias, x2, bias2, res, scale)
+    assert C.rel_l2(got0, ref0) < TOL
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 16, 8), (1, 128, 32, 32), (2, 16, 8, 8), (1, 512, 4, 4),
                                    (1, 256, 64, 64)])
 @pytest.mark.parametrize("silu", [True, False])
