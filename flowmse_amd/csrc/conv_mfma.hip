@@ -478,10 +478,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
 // exactly once per block, the GroupNorm + SiLU of the consuming ResnetBlock (layerspp.py:246,265: Conv(act(GN(x))))
 // is applied right there, on the way into LDS -- the normalised tensor never exists in HBM.  Zero padding stays
 // exact: out-of-image halo pixels are written as 0 AFTER the activation.
+// x * sigmoid(x) with v_exp_f32 / v_rcp_f32 (about 2 ulp)
+__device__ __forceinline__ float fast_silu(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 #ifndef FLOWSE_HTAP
 #define FLOWSE_HTAP 1
 #endif
-template <int WM, int WN, int TM, int TN, bool GN>
+// GN: 0 = plain input, 1 = GroupNorm affine while staging, 2 = GroupNorm + SiLU
+template <int WM, int WN, int TM, int TN, int GN>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(ConvArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
     static_assert(BM == 128 && NT == 256, "8x16 pixel tile, 4 waves");
@@ -561,10 +565,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(ConvArgs 
         v.z = __uint_as_float(rh[q].z); v.w = __uint_as_float(rh[q].w);
         v.x = fmaf(v.x - g_mu.x, g_sc.x, g_be.x); v.y = fmaf(v.y - g_mu.y, g_sc.y, g_be.y);
         v.z = fmaf(v.z - g_mu.z, g_sc.z, g_be.z); v.w = fmaf(v.w - g_mu.w, g_sc.w, g_be.w);
-        if (a.gn_silu) {
-            v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
-            v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
-        }
+        if (GN == 2) { v.x = fast_silu(v.x); v.y = fast_silu(v.y); v.z = fast_silu(v.z); v.w = fast_silu(v.w); }
         rh[q].x = in ? __float_as_uint(v.x) : 0u; rh[q].y = in ? __float_as_uint(v.y) : 0u;
         rh[q].z = in ? __float_as_uint(v.z) : 0u; rh[q].w = in ? __float_as_uint(v.w) : 0u;
     };
@@ -843,16 +844,20 @@ static int launch_halo(const ConvArgs& a, hipStream_t s) {
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static bool attr_done = false;
     if (!attr_done) {
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, TM, TN, false>),
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, TM, TN, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, TM, TN, true>),
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, TM, TN, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, TM, TN, 2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    if (a.gn.mean)
-        hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, TM, TN, true>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    if (a.gn.mean && a.gn_silu)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, TM, TN, 2>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    else if (a.gn.mean)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, TM, TN, 1>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     else
-        hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, TM, TN, false>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, TM, TN, 0>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
@@ -872,7 +877,10 @@ static int launch_halo(const ConvArgs& a, hipStream_t s) {
 // same way); the weights are pre-transformed (launch_wino_weights, [Cout][kx][component][Cin]).  One K step =
 // (32-channel chunk, kx): 4 components x 64 channels x 32 weights = one 36 KB LDS tile, single-buffered
 // (registers hold the next one), which keeps two blocks per CU.
-template <bool GN>
+#ifndef FLOWSE_EXP_NOBAR2
+#define FLOWSE_EXP_NOBAR2 0
+#endif
+template <int GN>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     constexpr int BN = 64, NT = 256;
     constexpr int HROWS = 180;                           // 10 x 18 halo pixels
@@ -950,10 +958,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         v.z = __uint_as_float(rh[q].z); v.w = __uint_as_float(rh[q].w);
         v.x = fmaf(v.x - g_mu.x, g_sc.x, g_be.x); v.y = fmaf(v.y - g_mu.y, g_sc.y, g_be.y);
         v.z = fmaf(v.z - g_mu.z, g_sc.z, g_be.z); v.w = fmaf(v.w - g_mu.w, g_sc.w, g_be.w);
-        if (a.gn_silu) {
-            v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
-            v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
-        }
+        if (GN == 2) { v.x = fast_silu(v.x); v.y = fast_silu(v.y); v.z = fast_silu(v.z); v.w = fast_silu(v.w); }
         rh[q].x = in ? __float_as_uint(v.x) : 0u; rh[q].y = in ? __float_as_uint(v.y) : 0u;
         rh[q].z = in ? __float_as_uint(v.z) : 0u; rh[q].w = in ? __float_as_uint(v.w) : 0u;
     };
@@ -1000,43 +1005,79 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     lstoreB();
     __syncthreads();
 
+    // Operand pipeline inside a step: the fragments of k-block j+1 (four halo rows, four weight components) are
+    // requested before the MFMAs of block j and turned into the Winograd operands d0-d2, d1+d2, d2-d1, d1-d3 (in
+    // place) by VALU instructions placed between those MFMAs, so neither the LDS latency nor the transform sits
+    // on the matrix pipe's critical path.
+#define FLOWSE_WLOAD(J, D, BF)                                                                                       \
+    {                                                                                                                \
+        const float* Ha = Hs + abase + kx * LDS_ROW + (J) * 8;                                                       \
+        D[0] = *reinterpret_cast<const float4*>(Ha);                                                                 \
+        D[1] = *reinterpret_cast<const float4*>(Ha + 18 * LDS_ROW);                                                  \
+        D[2] = *reinterpret_cast<const float4*>(Ha + 36 * LDS_ROW);                                                  \
+        D[3] = *reinterpret_cast<const float4*>(Ha + 54 * LDS_ROW);                                                  \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                \
+            BF[c] = *reinterpret_cast<const float4*>(Bw + c * BN * LDS_ROW + (J) * 8);                               \
+    }
+#define FLOWSE_WX03(D)                                                                                               \
+    {                                                                                                                \
+        D[0].x -= D[2].x; D[0].y -= D[2].y; D[0].z -= D[2].z; D[0].w -= D[2].w;                                      \
+        D[3].x = D[1].x - D[3].x; D[3].y = D[1].y - D[3].y; D[3].z = D[1].z - D[3].z; D[3].w = D[1].w - D[3].w;      \
+    }
+#define FLOWSE_WX12(D)                                                                                               \
+    {                                                                                                                \
+        const float4 t1 = D[1];                                                                                      \
+        D[1].x += D[2].x; D[1].y += D[2].y; D[1].z += D[2].z; D[1].w += D[2].w;                                      \
+        D[2].x -= t1.x; D[2].y -= t1.y; D[2].z -= t1.z; D[2].w -= t1.w;                                              \
+    }
+#define FLOWSE_WMMA4(V, BF, K)                                                                                       \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                    \
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].K, BF[c].K, acc[c], 0, 0, 0);
+    // MFMAs of the current block; the transform of the next block (DN) -- and, in the GroupNorm variants, one
+    // staged halo quad (XQ) -- sit between them as VALU blocks fenced off from the scheduler, which would otherwise
+    // sink every transform to just before the MFMA that consumes it and the LDS reads right in front of that
+#define FLOWSE_FENCE __builtin_amdgcn_sched_barrier(0);
+#define FLOWSE_WMMA(V, BF, DN, XQ)                                                                                   \
+    FLOWSE_WMMA4(V, BF, x) FLOWSE_FENCE                                                                              \
+    if (GN && kx >= 1) xform1((kx - 1) * 3 + (XQ));                                                                  \
+    FLOWSE_FENCE FLOWSE_WMMA4(V, BF, y) FLOWSE_FENCE                                                                 \
+    FLOWSE_WX03(DN) FLOWSE_FENCE FLOWSE_WMMA4(V, BF, z) FLOWSE_FENCE                                                 \
+    FLOWSE_WX12(DN) FLOWSE_FENCE FLOWSE_WMMA4(V, BF, w) FLOWSE_FENCE
+#define FLOWSE_WMMA_LAST(V, BF)                                                                                      \
+    FLOWSE_WMMA4(V, BF, x) FLOWSE_WMMA4(V, BF, y) FLOWSE_WMMA4(V, BF, z) FLOWSE_WMMA4(V, BF, w)
 #define FLOWSE_WSTEP(KX)                                                                                             \
     {                                                                                                                \
         constexpr int kx = KX;                                                                                       \
         const int s = chunk * 3 + kx;                                                                                \
         gloadB(min(s + 1, S_all - 1));                                                                               \
         if (kx == 0) gloadH(min(chunk + 1, nchunks - 1));                                                            \
-        if (kx == 1) { xform1(0); xform1(1); xform1(2); }                                                            \
-        if (kx == 2) { xform1(3); xform1(4); xform1(5); }                                                            \
-        _Pragma("unroll") for (int j = 0; j < KC / 8; ++j) {                                                         \
-            const float* Ha = Hs + abase + kx * LDS_ROW + j * 8;                                                     \
-            const float4 d0 = *reinterpret_cast<const float4*>(Ha);                                                  \
-            const float4 d1 = *reinterpret_cast<const float4*>(Ha + 18 * LDS_ROW);                                   \
-            const float4 d2 = *reinterpret_cast<const float4*>(Ha + 36 * LDS_ROW);                                   \
-            const float4 d3 = *reinterpret_cast<const float4*>(Ha + 54 * LDS_ROW);                                   \
-            float4 bf[4], v[4];                                                                                      \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                            \
-                bf[c] = *reinterpret_cast<const float4*>(Bw + c * BN * LDS_ROW + j * 8);                             \
-            v[0] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);                                  \
-            v[1] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);                                  \
-            v[2] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);                                  \
-            v[3] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);                                  \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].x, bf[c].x, acc[c], 0, 0, 0);                     \
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].y, bf[c].y, acc[c], 0, 0, 0);                     \
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].z, bf[c].z, acc[c], 0, 0, 0);                     \
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].w, bf[c].w, acc[c], 0, 0, 0);                     \
-            }                                                                                                        \
-        }                                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        FLOWSE_WLOAD(0, dA, bA)                                                                                      \
+        FLOWSE_WX03(dA) FLOWSE_WX12(dA)                                                                              \
+        FLOWSE_FENCE                                                                                                 \
+        FLOWSE_WLOAD(1, dB, bB) FLOWSE_FENCE                                                                         \
+        FLOWSE_WMMA(dA, bA, dB, 0)                                                                                   \
+        FLOWSE_WLOAD(2, dA, bA) FLOWSE_FENCE                                                                         \
+        FLOWSE_WMMA(dB, bB, dA, 1)                                                                                   \
+        FLOWSE_WLOAD(3, dB, bB) FLOWSE_FENCE                                                                         \
+        FLOWSE_WMMA(dA, bA, dB, 2)                                                                                   \
+        FLOWSE_WMMA_LAST(dB, bB)                                                                                     \
+        FLOWSE_FENCE                                                                                                 \
         __syncthreads(); /* every wave has left this step's weight tile (and, at kx = 2, the chunk's halo) */        \
         lstoreB();                                                                                                   \
         if (kx == 2) lstoreH();                                                                                      \
         __syncthreads();                                                                                             \
     }
+    float4 dA[4], dB[4], bA[4], bB[4];
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         FLOWSE_WSTEP(0) FLOWSE_WSTEP(1) FLOWSE_WSTEP(2)
     }
+#undef FLOWSE_WLOAD
+#undef FLOWSE_WX03
+#undef FLOWSE_WX12
+#undef FLOWSE_WMMA4
+#undef FLOWSE_WMMA
+#undef FLOWSE_WMMA_LAST
+#undef FLOWSE_FENCE
 #undef FLOWSE_WSTEP
 
     // output transform in registers; accumulator register r of a 32x32 tile holds pair row (r&3) + 8*(r>>2) + 4*kh:
@@ -1090,16 +1131,20 @@ static int launch_wino(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (180 + 256) * LDS_ROW * sizeof(float);          // > the <2,2,2,1> epilogue's 43 KB
     static bool attr_done = false;
     if (!attr_done) {
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<false>),
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<true>),
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    if (a.gn.mean)
-        hipLaunchKernelGGL(conv3x3_wino_kernel<true>, dim3(grid), dim3(256), lds, s, a);
+    if (a.gn.mean && a.gn_silu)
+        hipLaunchKernelGGL(conv3x3_wino_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+    else if (a.gn.mean)
+        hipLaunchKernelGGL(conv3x3_wino_kernel<1>, dim3(grid), dim3(256), lds, s, a);
     else
-        hipLaunchKernelGGL(conv3x3_wino_kernel<false>, dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(conv3x3_wino_kernel<0>, dim3(grid), dim3(256), lds, s, a);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
@@ -1206,7 +1251,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = fmaf(v[e] - mu[e], sc[e], be[e]);
-                    if (a.gn_silu) t = __fdividef(t, 1.f + __expf(-t));
+                    if (a.gn_silu) t = fast_silu(t);
                     v[e] = in ? t : 0.f;
                 }
             }
