@@ -206,7 +206,7 @@ def main():
         "achieved_TFLOPs_whole_path": value * nfe_per_step * FLOP_PER_FRAME_NFE / world / 1e12,
     }
     if rank == 0:
-        dom = prof.get("conv3x3_halo_gn_128x128")
+        dom = prof.get("dominant_conv3x3")
         if dom and dom["ms"] > 0:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
@@ -217,11 +217,20 @@ def main():
                 if k:
                     traffic = tj["kernels"][k]["hbm_bytes_per_launch"]
                     traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes)"
-            out["roofline"] = {"bound": "mfma",
-                               "kernel": "flowse::conv3x3_halo_kernel<2,2,2,2,true> (fp32 implicit-GEMM 3x3 conv, 128x128 tile, "
-                                         "LDS halo, fused GroupNorm+SiLU input)",
+            winograd = args.precision == "fp32" and not os.environ.get("FLOWSE_NO_WINOGRAD")
+            kname = ("flowse::conv3x3_wino_kernel<2> (fp32 F(2,3)-Winograd implicit-GEMM 3x3 conv, 8x16 pixel x 64 "
+                     "channel tile, LDS halo, fused GroupNorm+SiLU input)" if winograd else
+                     "flowse::conv3x3_halo_kernel<2,2,2,2,2> (fp32 implicit-GEMM 3x3 conv, 128x128 tile, LDS halo, "
+                     "fused GroupNorm+SiLU input)" if args.precision == "fp32" else
+                     "flowse::conv3x3_halo_bf16_kernel (16-bit operand variant of the halo kernel)")
+            issued = ach * (2.0 / 3.0 if winograd else 1.0)
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                               "frac": ach / PEAK_FP32_MATRIX_TFLOPS,
+                               "achieved_definition": "algorithmic direct-convolution FLOPs (SURVEY 8d) / launch time"
+                                                      + ("; F(2,3) issues 2/3 of them on the matrix cores" if winograd else ""),
+                               "mfma_issued": issued, "mfma_issued_frac": issued / PEAK_FP32_MATRIX_TFLOPS,
+                               "traffic": traffic, "traffic_source": traffic_src,
                                "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                                "flops_per_launch_avg": dom["flops"] / dom["launches"],
                                "algorithmic_bytes_per_launch_avg": dom["bytes"] / dom["launches"],

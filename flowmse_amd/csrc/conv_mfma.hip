@@ -809,9 +809,9 @@ int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps) {
 }
 
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
-    if (Cout <= 64) return 1;
     const int64_t M = (int64_t)B * H * W;
-    const int64_t tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
+    const int bn = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;       // N tile launch_conv picks for this width
+    const int64_t tiles = ((M + 127) / 128) * ((Cout + bn - 1) / bn);
     const int steps = ((Cin + KC - 1) / KC) * taps;
     if (tiles >= 256 || steps < 8) return 1;          // measured: 256 beats 128 and 64 at B = 1..8
     int64_t want = (512 + tiles - 1) / tiles;
@@ -1525,18 +1525,14 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
         set_error("conv: fused GroupNorm input requested for a shape the halo kernel does not cover");
         return ERR_ARG;
     }
-    if (a.Cout <= 32) return launch_cfg<4, 1, 1, 1>(a, s);
-    if (a.Cout <= 64) return launch_cfg<2, 2, 2, 1>(a, s);
-    if (a.ksplit > 1) {
-        if (!a.partial) {
-            set_error("conv: split-K needs a partial buffer");
-            return ERR_ARG;
-        }
-        const int rc = launch_cfg<2, 2, 2, 2>(a, s);
-        if (rc != OK || !with_reduce) return rc;
-        return launch_splitk_reduce(a, s);
+    if (a.ksplit > 1 && !a.partial) {
+        set_error("conv: split-K needs a partial buffer");
+        return ERR_ARG;
     }
-    return launch_cfg<2, 2, 2, 2>(a, s);
+    const int rc = a.Cout <= 32 ? launch_cfg<4, 1, 1, 1>(a, s)
+                 : a.Cout <= 64 ? launch_cfg<2, 2, 2, 1>(a, s) : launch_cfg<2, 2, 2, 2>(a, s);
+    if (rc != OK || a.ksplit <= 1 || !with_reduce) return rc;
+    return launch_splitk_reduce(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

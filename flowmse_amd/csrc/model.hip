@@ -891,7 +891,7 @@ static int run_plan(flowse_model* m, Plan* p, hipStream_t s) {
         const bool prof = m->prof_mode == 1 || (m->prof_mode == 0 && p->dominant[i]);
         flowse_model::Pending pd;
         if (prof) {
-            const std::string& name = (m->prof_mode == 0) ? std::string("conv3x3_halo_gn_128x128") : p->labels[i];
+            const std::string& name = (m->prof_mode == 0) ? std::string("dominant_conv3x3") : p->labels[i];
             auto it = m->prof_label_ix.find(name);
             if (it == m->prof_label_ix.end()) {
                 it = m->prof_label_ix.emplace(name, (int)m->prof_labels.size()).first;
