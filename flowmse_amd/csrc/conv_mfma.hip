@@ -872,24 +872,22 @@ static int launch_halo(const ConvArgs& a, hipStream_t s) {
 // i.e. 4 multiplies where the direct form spends 6: the matrix cores execute 2/3 of the direct-convolution FLOPs.
 // The block still owns an 8 x 16 pixel tile = 64 row pairs (4 x 16) and BN = 64 output channels; the GEMM rows are
 // the PAIRS, each wave accumulates the four components of a 32-pair x 32-channel tile (4 x 16 accumulators) and
-// combines them once, in registers, before the shared epilogue.  The input transform costs four VALU subtractions
-// per float4 fragment, taken from the same LDS halo tile the direct kernel stages (GroupNorm + SiLU fused in the
-// same way); the weights are pre-transformed (launch_wino_weights, [Cout][kx][component][Cin]).  One K step =
-// (32-channel chunk, kx): 4 components x 64 channels x 32 weights = one 36 KB LDS tile, single-buffered
-// (registers hold the next one), which keeps two blocks per CU.
-#ifndef FLOWSE_EXP_NOBAR2
-#define FLOWSE_EXP_NOBAR2 0
-#endif
+// combines them once, in registers, before the shared epilogue.
+//   A side: the same LDS halo tile the direct kernel stages (GroupNorm + SiLU fused the same way), double-buffered
+//           per 32-channel chunk (ONE barrier per chunk); the input transform is four VALU subtractions per float4
+//           fragment, done one k-block ahead between the MFMAs.
+//   B side: the pre-transformed weights are stored in MFMA FRAGMENT ORDER (launch_wino_weights:
+//           [Cout/32][kx][Cin/32][component][k-block][lane][4]), so each wave fetches its B operand with one fully
+//           coalesced 1 KB buffer load per (component, k-block), straight from L2 into registers, one k-block ahead:
+//           no LDS staging, no LDS writes and no barrier for the weights.
 template <int GN>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     constexpr int BN = 64, NT = 256;
     constexpr int HROWS = 180;                           // 10 x 18 halo pixels
     constexpr int H_LOADS = 6;
-    constexpr int BROWS = 4 * BN;                        // weight rows per step: [component][channel]
-    constexpr int B_LOADS = BROWS * 8 / NT;              // 8 float4 per thread
+    constexpr int HBUF = HROWS * LDS_ROW;                // floats per halo buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Hs = smem;                                    // [HROWS][LDS_ROW]
-    float* Bs = smem + HROWS * LDS_ROW;                  // [BROWS][LDS_ROW]
+    float* Hs = smem;                                    // [2][HROWS][LDS_ROW]
 
     const int tid = threadIdx.x;
     const int H = a.H, W = a.W, HW = H * W;
@@ -916,13 +914,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         hvo2[q] = in ? (unsigned)((hy * W + hx) * C2 + col4 * 4) * 4u : OOB;
         hin |= in ? (1u << q) : 0u;
     }
-    unsigned bvo[B_LOADS];                               // weight row r = row0 + 32q: component r / 64, channel r % 64
-#pragma unroll
-    for (int q = 0; q < B_LOADS; ++q) {
-        const int r = row0 + 32 * q;
-        const int n = n0 + (r & 63);
-        bvo[q] = (unsigned)((n * 12 + (r >> 6)) * Cin + col4 * 4) * 4u;
-    }
     const int64_t wbase = (int64_t)m_tl - W - 1;
     const int wpix = 9 * W + 18;
     const __amdgpu_buffer_rsrc_t rsrc1 =
@@ -932,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rsrcw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wino), 0, a.Cout * 12 * Cin * 4, 0x00020000);
 
-    u32x4 rh[H_LOADS], rb[B_LOADS];
+    u32x4 rh[H_LOADS];
     float4 g_mu, g_sc, g_be;
 
     auto gloadH = [&](int chunk) {
@@ -962,31 +953,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         rh[q].x = in ? __float_as_uint(v.x) : 0u; rh[q].y = in ? __float_as_uint(v.y) : 0u;
         rh[q].z = in ? __float_as_uint(v.z) : 0u; rh[q].w = in ? __float_as_uint(v.w) : 0u;
     };
-    auto lstoreH = [&]() {
+    auto lstoreH = [&](int buf) {
+        float* Hb = Hs + buf * HBUF;
 #pragma unroll
         for (int q = 0; q < H_LOADS; ++q) {
             const int hr = row0 + 32 * q;
-            if (hr < HROWS) *reinterpret_cast<u32x4*>(Hs + hr * LDS_ROW + col4 * 4) = rh[q];
+            if (hr < HROWS) *reinterpret_cast<u32x4*>(Hb + hr * LDS_ROW + col4 * 4) = rh[q];
         }
     };
-    auto gloadB = [&](int s) {                           // step s = chunk * 3 + kx
-        const int chunk = s / 3, kx = s - chunk * 3;
-        const unsigned soff_b = (unsigned)(kx * 4 * Cin + chunk * KC) * 4u;
-#pragma unroll
-        for (int q = 0; q < B_LOADS; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo[q], soff_b, 0);
-    };
-    auto lstoreB = [&]() {
-#pragma unroll
-        for (int q = 0; q < B_LOADS; ++q)
-            *reinterpret_cast<u32x4*>(Bs + (row0 + 32 * q) * LDS_ROW + col4 * 4) = rb[q];
-    };
 
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, kh = lane >> 5;
     // this lane's pair: tile row pair 2*wm + (li >> 4), column li & 15; its four input rows start at halo row 2*pair
     const int abase = ((2 * (2 * wm + (li >> 4))) * 18 + (li & 15)) * LDS_ROW + kh * 4;
-    const float* Bw = Bs + (wn * 32 + li) * LDS_ROW + kh * 4;
+    // weight fragments: 16 KB per (32-channel slice, kx, chunk), [component][k-block][lane][4 floats]
+    const int nchunks = Cin / KC;
+    const unsigned wslice = (unsigned)((n0 >> 5) + wn) * 3u * (unsigned)nchunks;     // in 16 KB units
+    const unsigned wvo = (unsigned)lane * 16u;
 
     f32x16 acc[4];                                       // the four Winograd components
 #pragma unroll
@@ -994,30 +979,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-    const int nchunks = Cin / KC;
-    const int S_all = nchunks * 3;
-
     gloadH(0);
-    gloadB(0);
 #pragma unroll
     for (int q = 0; q < H_LOADS; ++q) xform1(q);
-    lstoreH();
-    lstoreB();
+    lstoreH(0);
     __syncthreads();
 
-    // Operand pipeline inside a step: the fragments of k-block j+1 (four halo rows, four weight components) are
-    // requested before the MFMAs of block j and turned into the Winograd operands d0-d2, d1+d2, d2-d1, d1-d3 (in
-    // place) by VALU instructions placed between those MFMAs, so neither the LDS latency nor the transform sits
-    // on the matrix pipe's critical path.
-#define FLOWSE_WLOAD(J, D, BF)                                                                                       \
+    // Operand pipeline: the operands of k-block j+1 (four halo rows from LDS, four weight components from L2) are
+    // requested before the MFMAs of block j; the halo rows are turned into the Winograd operands d0-d2, d1+d2,
+    // d2-d1, d1-d3 (in place) by VALU blocks fenced between those MFMAs, so neither the load latency nor the
+    // transform sits on the matrix pipe's critical path.  (Unfenced, hipcc sinks every transform to just before the
+    // MFMA that consumes it and the reads right in front of that.)
+#define FLOWSE_FENCE __builtin_amdgcn_sched_barrier(0);
+#define FLOWSE_WLOAD(KX, J, D, BF)                                                                                   \
     {                                                                                                                \
-        const float* Ha = Hs + abase + kx * LDS_ROW + (J) * 8;                                                       \
+        const float* Ha = Hcur + abase + (KX) * LDS_ROW + (J) * 8;                                                   \
         D[0] = *reinterpret_cast<const float4*>(Ha);                                                                 \
         D[1] = *reinterpret_cast<const float4*>(Ha + 18 * LDS_ROW);                                                  \
         D[2] = *reinterpret_cast<const float4*>(Ha + 36 * LDS_ROW);                                                  \
         D[3] = *reinterpret_cast<const float4*>(Ha + 54 * LDS_ROW);                                                  \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                \
-            BF[c] = *reinterpret_cast<const float4*>(Bw + c * BN * LDS_ROW + (J) * 8);                               \
+        const unsigned so = (wslice + (unsigned)(KX) * (unsigned)nchunks + (unsigned)chunk) * 16384u;                \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                              \
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, wvo + (c * 4 + (J)) * 1024, so, 0);         \
+            BF[c] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z),                   \
+                                __uint_as_float(t.w));                                                               \
+        }                                                                                                            \
     }
 #define FLOWSE_WX03(D)                                                                                               \
     {                                                                                                                \
@@ -1033,52 +1019,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 #define FLOWSE_WMMA4(V, BF, K)                                                                                       \
     _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                    \
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].K, BF[c].K, acc[c], 0, 0, 0);
-    // MFMAs of the current block; the transform of the next block (DN) -- and, in the GroupNorm variants, one
-    // staged halo quad (XQ) -- sit between them as VALU blocks fenced off from the scheduler, which would otherwise
-    // sink every transform to just before the MFMA that consumes it and the LDS reads right in front of that
-#define FLOWSE_FENCE __builtin_amdgcn_sched_barrier(0);
-#define FLOWSE_WMMA(V, BF, DN, XQ)                                                                                   \
+    // One k-block: request the NEXT block's operands (NKX, NJ -> DN, BN_), run this block's 16 MFMAs with the next
+    // block's transform and one staged halo quad (XQ >= 0) fenced in between
+#define FLOWSE_WPHASE(V, BF, NKX, NJ, DN, BN_, XQ)                                                                   \
+    FLOWSE_WLOAD(NKX, NJ, DN, BN_) FLOWSE_FENCE                                                                      \
     FLOWSE_WMMA4(V, BF, x) FLOWSE_FENCE                                                                              \
-    if (GN && kx >= 1) xform1((kx - 1) * 3 + (XQ));                                                                  \
+    if (GN && (XQ) >= 0) xform1((XQ) < 0 ? 0 : (XQ));                                                                \
     FLOWSE_FENCE FLOWSE_WMMA4(V, BF, y) FLOWSE_FENCE                                                                 \
     FLOWSE_WX03(DN) FLOWSE_FENCE FLOWSE_WMMA4(V, BF, z) FLOWSE_FENCE                                                 \
     FLOWSE_WX12(DN) FLOWSE_FENCE FLOWSE_WMMA4(V, BF, w) FLOWSE_FENCE
-#define FLOWSE_WMMA_LAST(V, BF)                                                                                      \
-    FLOWSE_WMMA4(V, BF, x) FLOWSE_WMMA4(V, BF, y) FLOWSE_WMMA4(V, BF, z) FLOWSE_WMMA4(V, BF, w)
-#define FLOWSE_WSTEP(KX)                                                                                             \
-    {                                                                                                                \
-        constexpr int kx = KX;                                                                                       \
-        const int s = chunk * 3 + kx;                                                                                \
-        gloadB(min(s + 1, S_all - 1));                                                                               \
-        if (kx == 0) gloadH(min(chunk + 1, nchunks - 1));                                                            \
-        FLOWSE_WLOAD(0, dA, bA)                                                                                      \
-        FLOWSE_WX03(dA) FLOWSE_WX12(dA)                                                                              \
-        FLOWSE_FENCE                                                                                                 \
-        FLOWSE_WLOAD(1, dB, bB) FLOWSE_FENCE                                                                         \
-        FLOWSE_WMMA(dA, bA, dB, 0)                                                                                   \
-        FLOWSE_WLOAD(2, dA, bA) FLOWSE_FENCE                                                                         \
-        FLOWSE_WMMA(dB, bB, dA, 1)                                                                                   \
-        FLOWSE_WLOAD(3, dB, bB) FLOWSE_FENCE                                                                         \
-        FLOWSE_WMMA(dA, bA, dB, 2)                                                                                   \
-        FLOWSE_WMMA_LAST(dB, bB)                                                                                     \
-        FLOWSE_FENCE                                                                                                 \
-        __syncthreads(); /* every wave has left this step's weight tile (and, at kx = 2, the chunk's halo) */        \
-        lstoreB();                                                                                                   \
-        if (kx == 2) lstoreH();                                                                                      \
-        __syncthreads();                                                                                             \
-    }
+
     float4 dA[4], dB[4], bA[4], bB[4];
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        FLOWSE_WSTEP(0) FLOWSE_WSTEP(1) FLOWSE_WSTEP(2)
+        const float* Hcur = Hs + (chunk & 1) * HBUF;
+        gloadH(min(chunk + 1, nchunks - 1));             // next chunk's halo: normalised at kx = 1, stored at kx = 2
+        FLOWSE_WLOAD(0, 0, dA, bA)
+        FLOWSE_WX03(dA) FLOWSE_WX12(dA)
+        FLOWSE_FENCE
+        FLOWSE_WPHASE(dA, bA, 0, 1, dB, bB, -1)
+        FLOWSE_WPHASE(dB, bB, 0, 2, dA, bA, -1)
+        FLOWSE_WPHASE(dA, bA, 0, 3, dB, bB, -1)
+        FLOWSE_WPHASE(dB, bB, 1, 0, dA, bA, -1)
+        FLOWSE_WPHASE(dA, bA, 1, 1, dB, bB, 0)
+        FLOWSE_WPHASE(dB, bB, 1, 2, dA, bA, 1)
+        FLOWSE_WPHASE(dA, bA, 1, 3, dB, bB, 2)
+        FLOWSE_WPHASE(dB, bB, 2, 0, dA, bA, 3)
+        FLOWSE_WPHASE(dA, bA, 2, 1, dB, bB, 4)
+        FLOWSE_WPHASE(dB, bB, 2, 2, dA, bA, 5)
+        lstoreH((chunk + 1) & 1);                        // the other buffer: nobody reads it during this chunk
+        FLOWSE_FENCE
+        FLOWSE_WPHASE(dA, bA, 2, 3, dB, bB, -1)
+        FLOWSE_WMMA4(dB, bB, x) FLOWSE_WMMA4(dB, bB, y) FLOWSE_WMMA4(dB, bB, z) FLOWSE_WMMA4(dB, bB, w)
+        FLOWSE_FENCE
+        __syncthreads();     // next chunk's halo is complete; everyone has left this chunk's
     }
 #undef FLOWSE_WLOAD
 #undef FLOWSE_WX03
 #undef FLOWSE_WX12
 #undef FLOWSE_WMMA4
-#undef FLOWSE_WMMA
-#undef FLOWSE_WMMA_LAST
+#undef FLOWSE_WPHASE
 #undef FLOWSE_FENCE
-#undef FLOWSE_WSTEP
 
     // output transform in registers; accumulator register r of a 32x32 tile holds pair row (r&3) + 8*(r>>2) + 4*kh:
     // registers 0-7 belong to the wave's first row pair, 8-15 to the second, which is exactly the split the direct
@@ -1095,6 +1075,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     conv_epilogue<2, 2, 2, 1>(a, outp, smem, m_tl, n0, M, HW, 0, W);
 }
 
+// [Cout][9][Cin] -> MFMA fragment order [Cout/32][kx][Cin/32][component][k-block j][lane = kh*32 + li][4]:
+// element (n = 32 t + li, ci = 32 chunk + 8 j + 4 kh + e)
 __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, int Cout, int Cin,
                                                            float* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (n, kx, ci)
@@ -1104,14 +1086,21 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     const int64_t n = idx / ((int64_t)3 * Cin);
     const float g0 = w[(n * 9 + 0 + kx) * Cin + ci], g1 = w[(n * 9 + 3 + kx) * Cin + ci],
                 g2 = w[(n * 9 + 6 + kx) * Cin + ci];
-    float* o = out + ((n * 3 + kx) * 4) * Cin + ci;
+    const int nchunks = Cin >> 5;
+    const int chunk = ci >> 5, j = (ci >> 3) & 3, kh = (ci >> 2) & 1, e = ci & 3;
+    const int lane = kh * 32 + (int)(n & 31);
+    float* o = out + ((((n >> 5) * 3 + kx) * nchunks + chunk) * 16 + j) * 256 + lane * 4 + e;   // component 0
     o[0] = g0;
-    o[(int64_t)Cin] = 0.5f * ((g0 + g2) + g1);
-    o[(int64_t)2 * Cin] = 0.5f * ((g0 + g2) - g1);
-    o[(int64_t)3 * Cin] = g2;
+    o[1024] = 0.5f * ((g0 + g2) + g1);
+    o[2048] = 0.5f * ((g0 + g2) - g1);
+    o[3072] = g2;
 }
 
 int launch_wino_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s) {
+    if ((Cout % 32) != 0 || (Cin % 32) != 0) {
+        set_error("wino_weights: Cout=%d Cin=%d must be multiples of 32", Cout, Cin);
+        return ERR_SHAPE;
+    }
     const int64_t n = (int64_t)Cout * 3 * Cin;
     hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w_packed, Cout, Cin, out);
     FLOWSE_LAUNCH_CHECK();
@@ -1128,7 +1117,7 @@ bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps)
 static int launch_wino(const ConvArgs& a, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int grid = (int)(M / 128) * (a.Cout / 64);
-    const size_t lds = (180 + 256) * LDS_ROW * sizeof(float);          // > the <2,2,2,1> epilogue's 43 KB
+    const size_t lds = 2 * 180 * LDS_ROW * sizeof(float);              // two halo buffers; > the <2,2,2,1> epilogue's 43 KB
     static bool attr_done = false;
     if (!attr_done) {
         FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0>),
