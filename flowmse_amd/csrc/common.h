@@ -115,13 +115,17 @@ struct ConvArgs {
     const void* wq = nullptr;
     int terms = 0;
     int wq_f16 = 0;     // 1: the planes hold IEEE half instead of bf16 (terms must be 1; BASELINE config 5)
-    // optional F(2,3) Winograd weights of a 3x3 conv, [Cout][kx = 3][component = 4][Cin] (launch_wino_weights):
-    // when set and the shape qualifies (conv_supports_wino) the fp32 halo kernel runs its Winograd variant
+    // optional Winograd weights of a 3x3 conv in MFMA fragment order (launch_wino_weights / launch_f43_weights):
+    // when set and the shape qualifies (conv_supports_wino) the fp32 halo kernel runs its Winograd variant,
+    // F(2,3) (wino_f43 = 0, 12 transformed taps per channel pair) or F(4,3) (wino_f43 = 1, 18 taps)
     const float* wino = nullptr;
+    int wino_f43 = 0;
 };
-// F(2,3) weight transform along the kernel's vertical axis: packed [Cout][9][Cin] -> [Cout][3][4][Cin], on device
+// Winograd weight transforms along the kernel's vertical axis, packed [Cout][9][Cin] -> fragment order, on device
 int launch_wino_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s);
-inline int64_t conv_wino_numel(int Cout, int Cin) { return (int64_t)Cout * 12 * Cin; }
+int launch_f43_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s);
+inline int64_t conv_wino_numel(int Cout, int Cin) { return (int64_t)Cout * 18 * Cin; }   // room for either form
+bool conv_wino_default_f43();       // FLOWSE_WINOGRAD=f23 selects the F(2,3) kernel for the model handle
 bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // host helper: split fp32 conv weights [Cout][Cin][3][3] into the packed bf16 planes described above
 void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst, bool f16 = false);

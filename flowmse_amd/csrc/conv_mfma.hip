@@ -30,6 +30,8 @@
 #include <cstring>
 #include <type_traits>
 
+#include <string>
+
 #include "common.h"
 
 namespace flowse {
@@ -52,16 +54,13 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // ---- shared epilogue.  The accumulators go through LDS (C/D layout of the 32x32 MFMA: col = lane & 31,
 // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) so that bias / per-sample bias / residual are read and the result
 // is written as coalesced float4 rows of the NHWC output.  Precondition: all waves are past their last LDS read.
-template <int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
-                                              int M, int HW, int split, int rowW = 0) {
+template <int WM, int WN, int TM, int TN, class Scatter>
+__device__ __forceinline__ void conv_epilogue_with(const ConvArgs& a, float* smem, int m0, int n0, int M, int HW,
+                                                   int split, int rowW, Scatter scatter) {
     // rowW == 0: tile row rr is flat pixel m0 + rr; rowW > 0: the tile is 8 x 16 pixels of an image with row
     // pitch rowW, m0 = its top-left pixel
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int li = lane & 31, kh = lane >> 5;
     constexpr int CROW = BN + 4;
     static_assert(BM * CROW <= 2 * (BM + BN) * LDS_ROW, "C tile must fit in the staging buffers");
     float* Cs = smem;                          // [BM][CROW]; safe: the last loop iteration ended with a barrier
@@ -91,15 +90,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
             rb2[k] = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)(m < M ? m / HW : 0) * a.bias2_stride + n);
         }
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                Cs[row * CROW + (wn * TN + jn) * 32 + li] = acc[i][jn][r];
-            }
+    scatter(Cs, CROW);                         // accumulators -> Cs[tile row][channel]
     __syncthreads();
     if (a.partial) {                           // split-K slice: raw partial sums, epilogue in splitk_reduce
         if (ncol) {
@@ -161,6 +152,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
             }
         }
     }
+}
+
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
+                                              int M, int HW, int split, int rowW = 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, kh = lane >> 5;
+    conv_epilogue_with<WM, WN, TM, TN>(a, smem, m0, n0, M, HW, split, rowW, [&](float* Cs, int CROW) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    Cs[row * CROW + (wn * TN + jn) * 32 + li] = acc[i][jn][r];
+                }
+    });
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -1107,11 +1117,329 @@ int launch_wino_weights(const float* w_packed, int Cout, int Cin, float* out, hi
     return OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// F(4,3) Winograd variant (same tile, same halo staging, same fragment-order weight stream as the F(2,3) kernel).
+//
+// Along the vertical axis FOUR output rows y..y+3 come from the six input rows d0..d5 = y-1..y+4 through six
+// products per horizontal tap -- 6 multiplies where the direct form spends 12, i.e. HALF of the direct-convolution
+// FLOPs on the matrix cores (interpolation points 0, +-1, +-2, inf):
+//     v = B^T d :  v0 = 4 d0 - 5 d2 + d4          v1 = (d3 + d4) - 4 (d1 + d2)     v2 = (d4 - d3) + 4 (d1 - d2)
+//                  v3 = (d4 - d2) + 2 (d3 - d1)    v4 = (d4 - d2) - 2 (d3 - d1)     v5 = 4 d1 - 5 d3 + d5
+//     u = G g   :  u0 = g0/4   u1 = -(g0+g1+g2)/6   u2 = -(g0-g1+g2)/6   u3 = g0/24 + g1/12 + g2/6
+//                  u4 = g0/24 - g1/12 + g2/6   u5 = g2
+//     out = A^T m: o0 = m0+m1+m2+m3+m4   o1 = m1-m2+2(m3-m4)   o2 = m1+m2+4(m3+m4)   o3 = m1-m2+8(m3-m4)+m5
+// The 8 x 16 pixel tile is 2 x 16 = 32 row QUADS = one 32-row MFMA tile, so all four waves work on the same quads:
+// wave (wn, ch) owns output channels 32 wn .. +31 and the component half ch (0: m0..m2 from d0..d4, 1: m3..m5 from
+// d1..d5) -- 3 x 16 accumulators per lane.  The two halves of A^T m are added in the epilogue's LDS tile.  fp32
+// error of the 1-D F(4,3) form is ~3x the direct sum's (6e-7 vs 2e-7 rel-L2 on unit-variance data).
+constexpr int F43_HROW = 18 * LDS_ROW + 24;   // words per halo pixel row: 4 rows = 0 mod 64 banks (quad 1 vs quad 0)
+
+template <int GN, int CH>
+__device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem) {
+    constexpr int BN = 64;
+    constexpr int HROWS = 180;                           // 10 x 18 halo pixels
+    constexpr int H_LOADS = 6;
+    constexpr int HBUF = 10 * F43_HROW;                  // floats per halo buffer
+    float* Hs = smem;                                    // [2][10][F43_HROW]
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int M = a.B * HW;
+    const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
+    const int n_ntiles = a.Cout / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
+    const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 3);
+    const int b = mt / tiles_img, tt = mt - b * tiles_img;
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int y0 = ty * 8, x0 = tx * 16, n0 = nt * BN;
+    const int m_tl = (b * H + y0) * W + x0;
+
+    const int col4 = tid & 7, row0 = tid >> 3;
+    unsigned hvo1[H_LOADS], hvo2[H_LOADS];
+    int hlds[H_LOADS];                                   // LDS word offset of this thread's halo quads
+    unsigned hin = 0;
+#pragma unroll
+    for (int q = 0; q < H_LOADS; ++q) {
+        const int hr = row0 + 32 * q;
+        const int hy = hr / 18, hx = hr - hy * 18;
+        const bool in = hr < HROWS && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+        hvo1[q] = in ? (unsigned)((hy * W + hx) * C1 + col4 * 4) * 4u : OOB;
+        hvo2[q] = in ? (unsigned)((hy * W + hx) * C2 + col4 * 4) * 4u : OOB;
+        hlds[q] = hr < HROWS ? hy * F43_HROW + hx * LDS_ROW + col4 * 4 : -1;
+        hin |= in ? (1u << q) : 0u;
+    }
+    const int64_t wbase = (int64_t)m_tl - W - 1;
+    const int wpix = 9 * W + 18;
+    const __amdgpu_buffer_rsrc_t rsrc1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1 + wbase * C1), 0, wpix * C1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(C2 ? a.in2 + wbase * C2 : a.in1), 0, C2 ? wpix * C2 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wino), 0, a.Cout * 18 * Cin * 4, 0x00020000);
+
+    u32x4 rh[H_LOADS];
+    float4 g_mu, g_sc, g_be;
+
+    auto gloadH = [&](int chunk) {
+        const int c0 = chunk * KC;
+        const bool second = c0 >= C1;
+        const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * 4u;
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q)
+            rh[q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, hvo2[q], soff, 0)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, hvo1[q], soff, 0);
+        if (GN) {
+            const int cg = c0 + col4 * 4;
+            g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
+            g_sc = *reinterpret_cast<const float4*>(a.gn.scale + (int64_t)b * Cin + cg);
+            g_be = *reinterpret_cast<const float4*>(a.gn.beta + cg);
+        }
+    };
+    auto xform1 = [&](int q) {
+        if (!GN) return;
+        const bool in = (hin >> q) & 1u;
+        float4 v;
+        v.x = __uint_as_float(rh[q].x); v.y = __uint_as_float(rh[q].y);
+        v.z = __uint_as_float(rh[q].z); v.w = __uint_as_float(rh[q].w);
+        v.x = fmaf(v.x - g_mu.x, g_sc.x, g_be.x); v.y = fmaf(v.y - g_mu.y, g_sc.y, g_be.y);
+        v.z = fmaf(v.z - g_mu.z, g_sc.z, g_be.z); v.w = fmaf(v.w - g_mu.w, g_sc.w, g_be.w);
+        if (GN == 2) { v.x = fast_silu(v.x); v.y = fast_silu(v.y); v.z = fast_silu(v.z); v.w = fast_silu(v.w); }
+        rh[q].x = in ? __float_as_uint(v.x) : 0u; rh[q].y = in ? __float_as_uint(v.y) : 0u;
+        rh[q].z = in ? __float_as_uint(v.z) : 0u; rh[q].w = in ? __float_as_uint(v.w) : 0u;
+    };
+    auto lstoreH = [&](int buf) {
+        float* Hb = Hs + buf * HBUF;
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q)
+            if (hlds[q] >= 0) *reinterpret_cast<u32x4*>(Hb + hlds[q]) = rh[q];
+    };
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1;                             // CH = wave >> 1 (template parameter)
+    const int li = lane & 31, kh = lane >> 5;
+    // this lane's quad: row quad li >> 4, column li & 15; its input rows start at halo row 4*quad (+1 for CH = 1)
+    const int abase = (4 * (li >> 4) + CH) * F43_HROW + (li & 15) * LDS_ROW + kh * 4;
+    // weight fragments: 24 KB per (32-channel slice, kx, chunk), [component 0..5][k-block][lane][4 floats]
+    const int nchunks = Cin / KC;
+    const unsigned wslice = (unsigned)((n0 >> 5) + wn) * 3u * (unsigned)nchunks;     // in 24 KB units
+    const unsigned wvo = (unsigned)lane * 16u + (unsigned)CH * 3u * 4096u;
+
+    f32x16 acc[3];                                       // this wave's three Winograd components
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    gloadH(0);
+#pragma unroll
+    for (int q = 0; q < H_LOADS; ++q) xform1(q);
+    lstoreH(0);
+    __syncthreads();
+
+#define FLOWSE_FENCE __builtin_amdgcn_sched_barrier(0);
+    // five halo rows + three weight components of k-block (KX, J)
+#define FLOWSE_WLOAD(KX, J, D, BF)                                                                                   \
+    {                                                                                                                \
+        const float* Ha = Hcur + abase + (KX) * LDS_ROW + (J) * 8;                                                   \
+        _Pragma("unroll") for (int r = 0; r < 5; ++r) D[r] = *reinterpret_cast<const float4*>(Ha + r * F43_HROW);    \
+        const unsigned so = (wslice + (unsigned)(KX) * (unsigned)nchunks + (unsigned)chunk) * 24576u;                \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                              \
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, wvo + (c * 4 + (J)) * 1024, so, 0);         \
+            BF[c] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z),                   \
+                                __uint_as_float(t.w));                                                               \
+        }                                                                                                            \
+    }
+#define FLOWSE_F4(OP) { OP(x) OP(y) OP(z) OP(w) }
+    // input transform, in place: D[0..2] become this wave's three operands.
+    // CH 0 (rows d0..d4): v0 = 4 d0 - 5 d2 + d4, v1 = (d3 + d4) - 4 (d1 + d2), v2 = (d4 - d3) + 4 (d1 - d2)
+    // CH 1 (rows d1..d5 as D[0..4]): v5 = 4 d1 - 5 d3 + d5 -> D[0];  v3 = (d4 - d2) + 2 (d3 - d1) -> D[1];
+    //                                v4 = (d4 - d2) - 2 (d3 - d1) -> D[2]
+#define FLOWSE_WXA(D)                                                                                                \
+    {                                                                                                                \
+        if (CH == 0) {                                                                                               \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
+                float* p0 = &D[0].x + e; const float d2 = (&D[2].x)[e], d4 = (&D[4].x)[e];                           \
+                *p0 = fmaf(4.f, *p0, fmaf(-5.f, d2, d4));                                                            \
+            }                                                                                                        \
+        } else {                                                                                                     \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
+                float* p0 = &D[0].x + e; const float d3 = (&D[2].x)[e], d5 = (&D[4].x)[e];                           \
+                *p0 = fmaf(4.f, *p0, fmaf(-5.f, d3, d5));                                                            \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+#define FLOWSE_WXB(D)                                                                                                \
+    {                                                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+            const float r1 = (&D[1].x)[e], r2 = (&D[2].x)[e], r3 = (&D[3].x)[e], r4 = (&D[4].x)[e];                  \
+            if (CH == 0) { /* r1..r4 = d1..d4 */                                                                     \
+                (&D[1].x)[e] = fmaf(-4.f, r1 + r2, r3 + r4);                                                         \
+                (&D[2].x)[e] = fmaf(4.f, r1 - r2, r4 - r3);                                                          \
+            } else {       /* D[0..4] = d1..d5: r1 = d2, r2 = d3, r3 = d4; d1 was consumed by WXA -> use saved */    \
+                const float d1 = (&S.x)[e];                                                                          \
+                (&D[1].x)[e] = fmaf(2.f, r2 - d1, r3 - r1);                                                          \
+                (&D[2].x)[e] = fmaf(-2.f, r2 - d1, r3 - r1);                                                         \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+#define FLOWSE_WMMA3(V, BF, K)                                                                                       \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                    \
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].K, BF[c].K, acc[c], 0, 0, 0);
+    // CH 1 needs d1 (= D[0] before WXA overwrites it) again in WXB: keep a copy
+#define FLOWSE_WSAVE(D) if (CH == 1) S = D[0];
+#define FLOWSE_WPHASE(V, BF, NKX, NJ, DN, BN_, XQ)                                                                   \
+    FLOWSE_WLOAD(NKX, NJ, DN, BN_) FLOWSE_FENCE                                                                      \
+    FLOWSE_WMMA3(V, BF, x) FLOWSE_FENCE                                                                              \
+    if (GN && (XQ) >= 0) xform1((XQ) < 0 ? 0 : (XQ));                                                                \
+    FLOWSE_FENCE FLOWSE_WMMA3(V, BF, y) FLOWSE_FENCE                                                                 \
+    FLOWSE_WSAVE(DN) FLOWSE_WXA(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, z) FLOWSE_FENCE                                 \
+    FLOWSE_WXB(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, w) FLOWSE_FENCE
+
+    float4 dA[5], dB[5], bA[3], bB[3], S;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const float* Hcur = Hs + (chunk & 1) * HBUF;
+        gloadH(min(chunk + 1, nchunks - 1));             // next chunk's halo: normalised on the way, stored late
+        FLOWSE_WLOAD(0, 0, dA, bA)
+        FLOWSE_WSAVE(dA) FLOWSE_WXA(dA) FLOWSE_WXB(dA)
+        FLOWSE_FENCE
+        FLOWSE_WPHASE(dA, bA, 0, 1, dB, bB, -1)
+        FLOWSE_WPHASE(dB, bB, 0, 2, dA, bA, -1)
+        FLOWSE_WPHASE(dA, bA, 0, 3, dB, bB, -1)
+        FLOWSE_WPHASE(dB, bB, 1, 0, dA, bA, -1)
+        FLOWSE_WPHASE(dA, bA, 1, 1, dB, bB, 0)
+        FLOWSE_WPHASE(dB, bB, 1, 2, dA, bA, 1)
+        FLOWSE_WPHASE(dA, bA, 1, 3, dB, bB, 2)
+        FLOWSE_WPHASE(dB, bB, 2, 0, dA, bA, 3)
+        FLOWSE_WPHASE(dA, bA, 2, 1, dB, bB, 4)
+        FLOWSE_WPHASE(dB, bB, 2, 2, dA, bA, 5)
+        lstoreH((chunk + 1) & 1);                        // the other buffer: nobody reads it during this chunk
+        FLOWSE_FENCE
+        FLOWSE_WPHASE(dA, bA, 2, 3, dB, bB, -1)
+        FLOWSE_WMMA3(dB, bB, x) FLOWSE_WMMA3(dB, bB, y) FLOWSE_WMMA3(dB, bB, z) FLOWSE_WMMA3(dB, bB, w)
+        FLOWSE_FENCE
+        __syncthreads();     // next chunk's halo is complete; everyone has left this chunk's
+    }
+#undef FLOWSE_WLOAD
+#undef FLOWSE_F4
+#undef FLOWSE_WXA
+#undef FLOWSE_WXB
+#undef FLOWSE_WMMA3
+#undef FLOWSE_WSAVE
+#undef FLOWSE_WPHASE
+#undef FLOWSE_FENCE
+
+    // This wave's half of A^T m, laid out like four 32-pixel tiles of the <2,2,2,1> epilogue: accumulator register
+    // r holds quad row (r&3) + 8*(r>>2) + 4*kh, i.e. row quad r >> 3; output row 4*quad + o is tile row pair
+    // 2*quad + (o >> 1), second row of the pair when o is odd -> tile-row index i = 2*(r>>3) + (o>>1), r' = (r&7) + 8*(o&1)
+    conv_epilogue_with<2, 2, 2, 1>(a, smem, m_tl, n0, M, HW, 0, W, [&](float* Cs, int CROW) {
+        float* Cw = Cs + wn * 32 + li;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == CH) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float o[4];
+                    if (CH == 0) {
+                        const float s12 = acc[1][r] + acc[2][r], d12 = acc[1][r] - acc[2][r];
+                        o[0] = acc[0][r] + s12; o[1] = d12; o[2] = s12; o[3] = d12;
+                    } else {       // acc[0] = m5, acc[1] = m3, acc[2] = m4
+                        const float s34 = acc[1][r] + acc[2][r], d34 = acc[1][r] - acc[2][r];
+                        o[0] = s34; o[1] = 2.f * d34; o[2] = 4.f * s34; o[3] = fmaf(8.f, d34, acc[0][r]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        // tile row of (quad r>>3, output row k, column bits of r)
+                        const int row = (2 * (r >> 3) + (k >> 1)) * 32 + ((r & 7) + 8 * (k & 1) & 3) +
+                                        8 * (((r & 7) + 8 * (k & 1)) >> 2) + 4 * kh;
+                        if (pass == 0) Cw[row * CROW] = o[k];
+                        else Cw[row * CROW] += o[k];
+                    }
+                }
+            }
+            if (pass == 0) __syncthreads();
+        }
+    });
+}
+
+template <int GN>
+__global__ __launch_bounds__(256, 2) void conv3x3_f43_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // waves 0,1: component half 0; waves 2,3: half 1.  Both bodies execute the same barriers.
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7)) conv3x3_f43_body<GN, 1>(a, smem);
+    else conv3x3_f43_body<GN, 0>(a, smem);
+}
+
+// [Cout][9][Cin] -> fragment order [Cout/32][kx][Cin/32][component 0..5][k-block j][lane][4]; stored component order:
+// 0,1,2 = u0,u1,u2 (wave half 0), 3,4,5 = u5,u3,u4 (wave half 1: operands D[0] = v5, D[1] = v3, D[2] = v4)
+__global__ __launch_bounds__(256) void f43_weights_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                          float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (n, kx, ci)
+    if (idx >= (int64_t)Cout * 3 * Cin) return;
+    const int ci = (int)(idx % Cin);
+    const int kx = (int)((idx / Cin) % 3);
+    const int64_t n = idx / ((int64_t)3 * Cin);
+    const float g0 = w[(n * 9 + 0 + kx) * Cin + ci], g1 = w[(n * 9 + 3 + kx) * Cin + ci],
+                g2 = w[(n * 9 + 6 + kx) * Cin + ci];
+    const int nchunks = Cin >> 5;
+    const int chunk = ci >> 5, j = (ci >> 3) & 3, kh = (ci >> 2) & 1, e = ci & 3;
+    const int lane = kh * 32 + (int)(n & 31);
+    float* o = out + ((((n >> 5) * 3 + kx) * nchunks + chunk) * 24 + j) * 256 + lane * 4 + e;   // component slot 0
+    const float s02 = g0 + g2;
+    o[0] = 0.25f * g0;
+    o[1024] = (s02 + g1) * (-1.f / 6.f);
+    o[2048] = (s02 - g1) * (-1.f / 6.f);
+    const float t = fmaf(g0, 1.f / 24.f, g2 * (1.f / 6.f)), h = g1 * (1.f / 12.f);
+    o[3072] = g2;            // u5
+    o[4096] = t + h;         // u3
+    o[5120] = t - h;         // u4
+}
+
+int launch_f43_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s) {
+    if ((Cout % 32) != 0 || (Cin % 32) != 0) {
+        set_error("f43_weights: Cout=%d Cin=%d must be multiples of 32", Cout, Cin);
+        return ERR_SHAPE;
+    }
+    const int64_t n = (int64_t)Cout * 3 * Cin;
+    hipLaunchKernelGGL(f43_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w_packed, Cout, Cin, out);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+static int launch_f43(const ConvArgs& a, hipStream_t s) {
+    const int64_t M = (int64_t)a.B * a.H * a.W;
+    const int grid = (int)(M / 128) * (a.Cout / 64);
+    const size_t lds = 2 * 10 * F43_HROW * sizeof(float);              // two halo buffers; > the epilogue's 43 KB
+    static bool attr_done = false;
+    if (!attr_done) {
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f43_kernel<0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f43_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f43_kernel<2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    if (a.gn.mean && a.gn_silu)
+        hipLaunchKernelGGL(conv3x3_f43_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+    else if (a.gn.mean)
+        hipLaunchKernelGGL(conv3x3_f43_kernel<1>, dim3(grid), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(conv3x3_f43_kernel<0>, dim3(grid), dim3(256), lds, s, a);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
 static const bool g_no_wino = getenv("FLOWSE_NO_WINOGRAD") != nullptr;
+bool conv_wino_default_f43() {
+    static const bool f23 = getenv("FLOWSE_WINOGRAD") && std::string(getenv("FLOWSE_WINOGRAD")) == "f23";
+    return !f23;
+}
 
 bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps) {
     return !g_no_wino && (Cout % 64) == 0 && conv_supports_fused_gn(B, H, W, C1, C2, Cout, taps) &&
-           (int64_t)Cout * 12 * (C1 + C2) * 4 < (1LL << 31);
+           (int64_t)Cout * 18 * (C1 + C2) * 4 < (1LL << 31);
 }
 
 static int launch_wino(const ConvArgs& a, hipStream_t s) {
@@ -1501,7 +1829,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
             set_error("conv: 16-bit path needs terms = 1 (bf16 / f16) or 3 (bf16 only)");
             return ERR_ARG;
         }
-        if (a.wino && conv_supports_wino(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) return launch_wino(a, s);
+        if (a.wino && conv_supports_wino(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))
+            return a.wino_f43 ? launch_f43(a, s) : launch_wino(a, s);
         if (a.Cout <= 32) return launch_halo<4, 1, 1, 1>(a, s);
         if (a.Cout <= 64) return launch_halo<2, 2, 2, 1>(a, s);
         // fewer than two 128x128 tiles per CU (single utterances): halve the N tile so that two blocks share every

@@ -605,7 +605,10 @@ struct Builder {
                 c.terms = terms;
                 c.wq_f16 = M->precision == 3 ? 1 : 0;
             }
-            if (wino_off >= 0) c.wino = M->d_wino + wino_off;
+            if (wino_off >= 0) {
+                c.wino = M->d_wino + wino_off;
+                c.wino_f43 = conv_wino_default_f43() ? 1 : 0;
+            }
             return c;
         };
         const double flops = 2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2);
@@ -1039,7 +1042,9 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
         m->d_wino_numel = wino_total;
     }
     for (auto& r : pk.wino) {
-        const int wrc = launch_wino_weights(m->d_w + r.off, r.Cout, r.Cin, m->d_wino + m->wino_of[r.off], nullptr);
+        float* dst = m->d_wino + m->wino_of[r.off];
+        const int wrc = conv_wino_default_f43() ? launch_f43_weights(m->d_w + r.off, r.Cout, r.Cin, dst, nullptr)
+                                                : launch_wino_weights(m->d_w + r.off, r.Cout, r.Cin, dst, nullptr);
         if (wrc != OK) return wrc;
     }
     FLOWSE_HIP(hipDeviceSynchronize());
@@ -1321,34 +1326,31 @@ int flowse_op_conv3x3_gn(const float* in1, int C1, const float* in2, int C2, con
     return launch_conv(c, s);
 }
 
-int64_t flowse_op_conv3x3_f23_scratch_floats(int B, int H, int W, int C, int Cout) {
-    return flowse_op_group_norm_scratch_floats(B, H * W, C) + conv_wino_numel(Cout, C);
-}
-
-int flowse_op_conv3x3_f23(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
-                          float eps, int silu, const float* w, const float* bias, const float* bias2, int bias2_stride,
-                          const float* res, float* out, int B, int H, int W, int Cout, float scale, float* scratch,
-                          void* stream) {
+static int op_conv3x3_winograd(int f43, const float* in1, int C1, const float* in2, int C2, const float* gamma,
+                               const float* beta, float eps, int silu, const float* w, const float* bias,
+                               const float* bias2, int bias2_stride, const float* res, float* out, int B, int H, int W,
+                               int Cout, float scale, float* scratch, void* stream) {
     if (!in1 || !w || !out || !scratch || (gamma && !beta)) {
-        set_error("flowse_op_conv3x3_f23: null argument");
+        set_error("flowse_op_conv3x3_f23/f43: null argument");
         return ERR_ARG;
     }
     if (!in2) C2 = 0;
     if (!conv_supports_wino(B, H, W, C1, C2, Cout, 9)) {
-        set_error("flowse_op_conv3x3_f23: shape B=%d H=%d W=%d C=%d+%d Cout=%d not covered by the Winograd kernel", B,
+        set_error("flowse_op_conv3x3_f23/f43: shape B=%d H=%d W=%d C=%d+%d Cout=%d not covered by the Winograd kernel", B,
                   H, W, C1, C2, Cout);
         return ERR_SHAPE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int C = C1 + C2, HW = H * W;
     float* wf = scratch + flowse_op_group_norm_scratch_floats(B, HW, C);
-    int rc = launch_wino_weights(w, Cout, C, wf, s);
+    int rc = f43 ? launch_f43_weights(w, Cout, C, wf, s) : launch_wino_weights(w, Cout, C, wf, s);
     if (rc != OK) return rc;
     ConvArgs c;
     c.in1 = in1; c.in2 = in2; c.C1 = C1; c.C2 = C2;
     c.w = w; c.bias = bias; c.bias2 = bias2; c.bias2_stride = bias2_stride; c.res = res; c.out = out;
     c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = 9; c.scale = scale;
     c.wino = wf;
+    c.wino_f43 = f43;
     if (gamma) {
         const int G = std::min(C / 4, 32);
         const int nblk = gn_partial_blocks(HW, C);
@@ -1363,6 +1365,25 @@ int flowse_op_conv3x3_f23(const float* in1, int C1, const float* in2, int C2, co
         c.gn_silu = silu;
     }
     return launch_conv(c, s);
+}
+
+int64_t flowse_op_conv3x3_f23_scratch_floats(int B, int H, int W, int C, int Cout) {
+    return flowse_op_group_norm_scratch_floats(B, H * W, C) + conv_wino_numel(Cout, C);
+}
+
+int flowse_op_conv3x3_f23(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
+                          float eps, int silu, const float* w, const float* bias, const float* bias2, int bias2_stride,
+                          const float* res, float* out, int B, int H, int W, int Cout, float scale, float* scratch,
+                          void* stream) {
+    return op_conv3x3_winograd(0, in1, C1, in2, C2, gamma, beta, eps, silu, w, bias, bias2, bias2_stride, res, out, B, H,
+                               W, Cout, scale, scratch, stream);
+}
+int flowse_op_conv3x3_f43(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
+                          float eps, int silu, const float* w, const float* bias, const float* bias2, int bias2_stride,
+                          const float* res, float* out, int B, int H, int W, int Cout, float scale, float* scratch,
+                          void* stream) {
+    return op_conv3x3_winograd(1, in1, C1, in2, C2, gamma, beta, eps, silu, w, bias, bias2, bias2_stride, res, out, B, H,
+                               W, Cout, scale, scratch, stream);
 }
 
 int flowse_op_fir_up(const float* in, float* out, int B, int H, int W, int C, void* stream) {

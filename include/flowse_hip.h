@@ -161,13 +161,19 @@ int flowse_op_conv3x3_gn(const float* in1, int C1, const float* in2, int C2, con
                          float eps, int silu, const float* w, const float* bias, const float* bias2,
                          int bias2_stride, const float* res, float* out, int B, int H, int W, int Cout, float scale,
                          float* scratch, void* stream);
-/* The same fused ResnetBlock half computed with the F(2,3) Winograd form of the 3x3 filter (vertical axis: 4
- * multiplies per output pair instead of 6, i.e. 2/3 of the direct-convolution FLOPs on the matrix cores) -- the
- * kernel the model handle uses for every 3x3 convolution with Cout % 64 == 0 on images large enough for the halo
- * kernel.  gamma == NULL: plain convolution without the GroupNorm + SiLU input stage.  `w` is the packed
- * [Cout][9][Cin] weight as for flowse_op_conv2d; the transformed weights are derived into `scratch`
- * (flowse_op_conv3x3_f23_scratch_floats floats).  Other shapes: FLOWSE_ERR_SHAPE. */
+/* The same fused ResnetBlock half computed with a Winograd form of the 3x3 filter along its vertical axis --
+ * F(2,3): 4 multiplies per output pair instead of 6 (2/3 of the direct-convolution FLOPs on the matrix cores);
+ * F(4,3): 6 multiplies per four outputs instead of 12 (1/2 of them; fp32 error ~3x the direct sum's) -- the kernels
+ * the model handle uses for every 3x3 convolution with Cout % 64 == 0 on images large enough for the halo kernel
+ * (F(4,3) by default, FLOWSE_WINOGRAD=f23 selects F(2,3), FLOWSE_NO_WINOGRAD=1 the direct kernel).
+ * gamma == NULL: plain convolution without the GroupNorm + SiLU input stage.  `w` is the packed [Cout][9][Cin]
+ * weight as for flowse_op_conv2d; the transformed weights are derived into `scratch`
+ * (flowse_op_conv3x3_f23_scratch_floats floats, enough for either form).  Other shapes: FLOWSE_ERR_SHAPE. */
 int flowse_op_conv3x3_f23(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
+                          float eps, int silu, const float* w, const float* bias, const float* bias2,
+                          int bias2_stride, const float* res, float* out, int B, int H, int W, int Cout, float scale,
+                          float* scratch, void* stream);
+int flowse_op_conv3x3_f43(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
                           float eps, int silu, const float* w, const float* bias, const float* bias2,
                           int bias2_stride, const float* res, float* out, int B, int H, int W, int Cout, float scale,
                           float* scratch, void* stream);

@@ -127,7 +127,7 @@ def conv3x3_gn(x1, gamma, beta, w, bias=None, x2=None, bias2=None, res=None, sca
 
 
 def conv3x3_f23(x1, w, gamma=None, beta=None, bias=None, x2=None, bias2=None, res=None, scale=1.0, silu=True,
-                eps=1e-6):
+                eps=1e-6, form="f23"):
     """Same contract as conv3x3_gn (gamma None: no normalisation) through the F(2,3) Winograd halo kernel."""
     Cout, Cin, k, _ = w.shape
     a1 = nhwc(x1)
@@ -142,7 +142,8 @@ def conv3x3_f23(x1, w, gamma=None, beta=None, bias=None, x2=None, bias2=None, re
     be = beta.cuda().contiguous() if beta is not None else None
     scratch = torch.empty(L.flowse_op_conv3x3_f23_scratch_floats(B, H, W, C1 + C2, Cout), device="cuda")
     out = torch.empty(B, H, W, Cout, device="cuda")
-    _lib.check(L.flowse_op_conv3x3_f23(_lib.ptr(a1), C1, _lib.ptr(a2), C2, _lib.ptr(g), _lib.ptr(be), eps, int(silu),
+    fn = L.flowse_op_conv3x3_f43 if form == "f43" else L.flowse_op_conv3x3_f23
+    _lib.check(fn(_lib.ptr(a1), C1, _lib.ptr(a2), C2, _lib.ptr(g), _lib.ptr(be), eps, int(silu),
                                        _lib.ptr(wp), _lib.ptr(bb), _lib.ptr(b2),
                                        b2.shape[1] if b2 is not None else 0, _lib.ptr(rr), _lib.ptr(out), B, H, W, Cout,
                                        float(scale), _lib.ptr(scratch), stream()))

@@ -145,8 +145,9 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("form", ["f23", "f43"])
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_conv3x3_winograd_f23(G, case):
+def test_conv3x3_winograd(G, case, form):
     """F(2,3) Winograd form of the halo kernel (with and without the fused GroupNorm + SiLU input stage) against
     the plain fp32 direct convolution; also against the direct HIP kernel on the same input."""
     B, H, W, C1, C2, Cout, has_b2, has_res, scale, silu = case
@@ -172,14 +173,14 @@ def test_conv3x3_winograd_f23(G, case):
         return t * scale
 
     ref = finish(F.conv2d(hn.double(), w.double(), bias.double(), padding=1).float())
-    got = G.conv3x3_f23(x1, w, g, be, bias, x2, bias2, res, scale, silu)
+    got = G.conv3x3_f23(x1, w, g, be, bias, x2, bias2, res, scale, silu, form=form)
     err = C.rel_l2(got, ref)
     direct = C.rel_l2(G.conv3x3_gn(x1, g, be, w, bias, x2, bias2, res, scale, silu), ref)
-    print(f"winograd rel-L2 {err:.2e}   direct kernel {direct:.2e}")
+    print(f"winograd {form} rel-L2 {err:.2e}   direct kernel {direct:.2e}")
     assert err < TOL
     # plain conv (no normalisation), unnormalised input with a DC offset: the row differences d0 - d2 cancel it
     ref0 = finish(F.conv2d(xin.double(), w.double(), bias.double(), padding=1).float())
-    got0 = G.conv3x3_f23(x1, w, None, None, bias, x2, bias2, res, scale)
+    got0 = G.conv3x3_f23(x1, w, None, None, bias, x2, bias2, res, scale, form=form)
     assert C.rel_l2(got0, ref0) < TOL
 
 
