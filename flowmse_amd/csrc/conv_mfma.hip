@@ -491,6 +491,33 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
 // x * sigmoid(x) with v_exp_f32 / v_rcp_f32 (about 2 ulp)
 __device__ __forceinline__ float fast_silu(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
+// GroupNorm affine (+ SiLU) of one staged channel quad, written on float2 halves so that hipcc emits the packed
+// fp32 VALU forms (v_pk_add / v_pk_fma / v_pk_mul); only v_exp_f32 / v_rcp_f32 stay scalar.  `keep` = 0 zeroes the
+// quad (halo pixel outside the image: zero padding applies AFTER the activation).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int GN>
+__device__ __forceinline__ u32x4 gn_quad(u32x4 raw, float4 mu, float4 sc, float4 be, bool keep) {
+    f32x2 lo = {__uint_as_float(raw.x), __uint_as_float(raw.y)}, hi = {__uint_as_float(raw.z), __uint_as_float(raw.w)};
+    const f32x2 mlo = {mu.x, mu.y}, mhi = {mu.z, mu.w}, slo = {sc.x, sc.y}, shi = {sc.z, sc.w};
+    const f32x2 blo = {be.x, be.y}, bhi = {be.z, be.w};
+    lo = __builtin_elementwise_fma(lo - mlo, slo, blo);
+    hi = __builtin_elementwise_fma(hi - mhi, shi, bhi);
+    if (GN == 2) {
+        const f32x2 nl2e = {-1.44269504088896341f, -1.44269504088896341f}, one = {1.f, 1.f};
+        f32x2 el = lo * nl2e, eh = hi * nl2e;
+        el.x = __builtin_amdgcn_exp2f(el.x); el.y = __builtin_amdgcn_exp2f(el.y);
+        eh.x = __builtin_amdgcn_exp2f(eh.x); eh.y = __builtin_amdgcn_exp2f(eh.y);
+        el += one; eh += one;
+        el.x = __builtin_amdgcn_rcpf(el.x); el.y = __builtin_amdgcn_rcpf(el.y);
+        eh.x = __builtin_amdgcn_rcpf(eh.x); eh.y = __builtin_amdgcn_rcpf(eh.y);
+        lo *= el; hi *= eh;
+    }
+    u32x4 o;
+    o.x = keep ? __float_as_uint(lo.x) : 0u; o.y = keep ? __float_as_uint(lo.y) : 0u;
+    o.z = keep ? __float_as_uint(hi.x) : 0u; o.w = keep ? __float_as_uint(hi.y) : 0u;
+    return o;
+}
+
 #ifndef FLOWSE_HTAP
 #define FLOWSE_HTAP 1
 #endif
@@ -569,15 +596,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(ConvArgs 
     // LDS write once every wave has left the previous chunk's halo.  v_exp / v_rcp based SiLU: ~2 ulp.
     auto xform1 = [&](int q) {
         if (!GN) return;
-        const bool in = (hin >> q) & 1u;
-        float4 v;
-        v.x = __uint_as_float(rh[q].x); v.y = __uint_as_float(rh[q].y);
-        v.z = __uint_as_float(rh[q].z); v.w = __uint_as_float(rh[q].w);
-        v.x = fmaf(v.x - g_mu.x, g_sc.x, g_be.x); v.y = fmaf(v.y - g_mu.y, g_sc.y, g_be.y);
-        v.z = fmaf(v.z - g_mu.z, g_sc.z, g_be.z); v.w = fmaf(v.w - g_mu.w, g_sc.w, g_be.w);
-        if (GN == 2) { v.x = fast_silu(v.x); v.y = fast_silu(v.y); v.z = fast_silu(v.z); v.w = fast_silu(v.w); }
-        rh[q].x = in ? __float_as_uint(v.x) : 0u; rh[q].y = in ? __float_as_uint(v.y) : 0u;
-        rh[q].z = in ? __float_as_uint(v.z) : 0u; rh[q].w = in ? __float_as_uint(v.w) : 0u;
+        rh[q] = gn_quad<GN>(rh[q], g_mu, g_sc, g_be, (hin >> q) & 1u);
     };
     auto xformH = [&]() {
 #pragma unroll
@@ -953,15 +972,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     };
     auto xform1 = [&](int q) {
         if (!GN) return;
-        const bool in = (hin >> q) & 1u;
-        float4 v;
-        v.x = __uint_as_float(rh[q].x); v.y = __uint_as_float(rh[q].y);
-        v.z = __uint_as_float(rh[q].z); v.w = __uint_as_float(rh[q].w);
-        v.x = fmaf(v.x - g_mu.x, g_sc.x, g_be.x); v.y = fmaf(v.y - g_mu.y, g_sc.y, g_be.y);
-        v.z = fmaf(v.z - g_mu.z, g_sc.z, g_be.z); v.w = fmaf(v.w - g_mu.w, g_sc.w, g_be.w);
-        if (GN == 2) { v.x = fast_silu(v.x); v.y = fast_silu(v.y); v.z = fast_silu(v.z); v.w = fast_silu(v.w); }
-        rh[q].x = in ? __float_as_uint(v.x) : 0u; rh[q].y = in ? __float_as_uint(v.y) : 0u;
-        rh[q].z = in ? __float_as_uint(v.z) : 0u; rh[q].w = in ? __float_as_uint(v.w) : 0u;
+        rh[q] = gn_quad<GN>(rh[q], g_mu, g_sc, g_be, (hin >> q) & 1u);
     };
     auto lstoreH = [&](int buf) {
         float* Hb = Hs + buf * HBUF;
@@ -1198,15 +1209,7 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     };
     auto xform1 = [&](int q) {
         if (!GN) return;
-        const bool in = (hin >> q) & 1u;
-        float4 v;
-        v.x = __uint_as_float(rh[q].x); v.y = __uint_as_float(rh[q].y);
-        v.z = __uint_as_float(rh[q].z); v.w = __uint_as_float(rh[q].w);
-        v.x = fmaf(v.x - g_mu.x, g_sc.x, g_be.x); v.y = fmaf(v.y - g_mu.y, g_sc.y, g_be.y);
-        v.z = fmaf(v.z - g_mu.z, g_sc.z, g_be.z); v.w = fmaf(v.w - g_mu.w, g_sc.w, g_be.w);
-        if (GN == 2) { v.x = fast_silu(v.x); v.y = fast_silu(v.y); v.z = fast_silu(v.z); v.w = fast_silu(v.w); }
-        rh[q].x = in ? __float_as_uint(v.x) : 0u; rh[q].y = in ? __float_as_uint(v.y) : 0u;
-        rh[q].z = in ? __float_as_uint(v.z) : 0u; rh[q].w = in ? __float_as_uint(v.w) : 0u;
+        rh[q] = gn_quad<GN>(rh[q], g_mu, g_sc, g_be, (hin >> q) & 1u);
     };
     auto lstoreH = [&](int buf) {
         float* Hb = Hs + buf * HBUF;
@@ -1239,12 +1242,15 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     __syncthreads();
 
 #define FLOWSE_FENCE __builtin_amdgcn_sched_barrier(0);
-    // five halo rows + three weight components of k-block (KX, J)
-#define FLOWSE_WLOAD(KX, J, D, BF)                                                                                   \
+    // five halo rows of k-block (KX, J) from LDS; three weight components of k-block (KX, J) of chunk CHK from L2
+#define FLOWSE_WLOADA(KX, J, D)                                                                                      \
     {                                                                                                                \
         const float* Ha = Hcur + abase + (KX) * LDS_ROW + (J) * 8;                                                   \
         _Pragma("unroll") for (int r = 0; r < 5; ++r) D[r] = *reinterpret_cast<const float4*>(Ha + r * F43_HROW);    \
-        const unsigned so = (wslice + (unsigned)(KX) * (unsigned)nchunks + (unsigned)chunk) * 24576u;                \
+    }
+#define FLOWSE_WLOADB(KX, J, CHK, BF)                                                                                \
+    {                                                                                                                \
+        const unsigned so = (wslice + (unsigned)(KX) * (unsigned)nchunks + (unsigned)(CHK)) * 24576u;                \
         _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                              \
             const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, wvo + (c * 4 + (J)) * 1024, so, 0);         \
             BF[c] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z),                   \
@@ -1289,39 +1295,50 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].K, BF[c].K, acc[c], 0, 0, 0);
     // CH 1 needs d1 (= D[0] before WXA overwrites it) again in WXB: keep a copy
 #define FLOWSE_WSAVE(D) if (CH == 1) S = D[0];
-#define FLOWSE_WPHASE(V, BF, NKX, NJ, DN, BN_, XQ)                                                                   \
-    FLOWSE_WLOAD(NKX, NJ, DN, BN_) FLOWSE_FENCE                                                                      \
+    // One k-block: request the next block's halo rows (one ahead, LDS) and the weights of the block after that (two
+    // ahead, L2 latency), run this block's 12 MFMAs with the next block's transform fenced in between
+#define FLOWSE_WPHASE(V, BF, NKX, NJ, DN, BKX, BJ, BCHK, BF2, XQ)                                                    \
+    FLOWSE_WLOADA(NKX, NJ, DN) FLOWSE_WLOADB(BKX, BJ, BCHK, BF2) FLOWSE_FENCE                                        \
     FLOWSE_WMMA3(V, BF, x) FLOWSE_FENCE                                                                              \
     if (GN && (XQ) >= 0) xform1((XQ) < 0 ? 0 : (XQ));                                                                \
     FLOWSE_FENCE FLOWSE_WMMA3(V, BF, y) FLOWSE_FENCE                                                                 \
     FLOWSE_WSAVE(DN) FLOWSE_WXA(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, z) FLOWSE_FENCE                                 \
     FLOWSE_WXB(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, w) FLOWSE_FENCE
 
-    float4 dA[5], dB[5], bA[3], bB[3], S;
+    float4 dA[5], dB[5], b0[3], b1[3], b2[3], S;
+    {
+        const int chunk = 0;
+        (void)chunk;
+        FLOWSE_WLOADB(0, 0, 0, b0)
+        FLOWSE_WLOADB(0, 1, 0, b1)
+    }
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const float* Hcur = Hs + (chunk & 1) * HBUF;
-        gloadH(min(chunk + 1, nchunks - 1));             // next chunk's halo: normalised on the way, stored late
-        FLOWSE_WLOAD(0, 0, dA, bA)
+        const int cnext = min(chunk + 1, nchunks - 1);
+        gloadH(cnext);                                   // next chunk's halo: normalised on the way, stored late
+        FLOWSE_WLOADA(0, 0, dA)
         FLOWSE_WSAVE(dA) FLOWSE_WXA(dA) FLOWSE_WXB(dA)
         FLOWSE_FENCE
-        FLOWSE_WPHASE(dA, bA, 0, 1, dB, bB, -1)
-        FLOWSE_WPHASE(dB, bB, 0, 2, dA, bA, -1)
-        FLOWSE_WPHASE(dA, bA, 0, 3, dB, bB, -1)
-        FLOWSE_WPHASE(dB, bB, 1, 0, dA, bA, -1)
-        FLOWSE_WPHASE(dA, bA, 1, 1, dB, bB, 0)
-        FLOWSE_WPHASE(dB, bB, 1, 2, dA, bA, 1)
-        FLOWSE_WPHASE(dA, bA, 1, 3, dB, bB, 2)
-        FLOWSE_WPHASE(dB, bB, 2, 0, dA, bA, 3)
-        FLOWSE_WPHASE(dA, bA, 2, 1, dB, bB, 4)
-        FLOWSE_WPHASE(dB, bB, 2, 2, dA, bA, 5)
+        FLOWSE_WPHASE(dA, b0, 0, 1, dB, 0, 2, chunk, b2, -1)
+        FLOWSE_WPHASE(dB, b1, 0, 2, dA, 0, 3, chunk, b0, -1)
+        FLOWSE_WPHASE(dA, b2, 0, 3, dB, 1, 0, chunk, b1, -1)
+        FLOWSE_WPHASE(dB, b0, 1, 0, dA, 1, 1, chunk, b2, -1)
+        FLOWSE_WPHASE(dA, b1, 1, 1, dB, 1, 2, chunk, b0, 0)
+        FLOWSE_WPHASE(dB, b2, 1, 2, dA, 1, 3, chunk, b1, 1)
+        FLOWSE_WPHASE(dA, b0, 1, 3, dB, 2, 0, chunk, b2, 2)
+        FLOWSE_WPHASE(dB, b1, 2, 0, dA, 2, 1, chunk, b0, 3)
+        FLOWSE_WPHASE(dA, b2, 2, 1, dB, 2, 2, chunk, b1, 4)
+        FLOWSE_WPHASE(dB, b0, 2, 2, dA, 2, 3, chunk, b2, 5)
         lstoreH((chunk + 1) & 1);                        // the other buffer: nobody reads it during this chunk
         FLOWSE_FENCE
-        FLOWSE_WPHASE(dA, bA, 2, 3, dB, bB, -1)
-        FLOWSE_WMMA3(dB, bB, x) FLOWSE_WMMA3(dB, bB, y) FLOWSE_WMMA3(dB, bB, z) FLOWSE_WMMA3(dB, bB, w)
+        FLOWSE_WPHASE(dA, b1, 2, 3, dB, 0, 0, cnext, b0, -1)
+        FLOWSE_WLOADB(0, 1, cnext, b1) FLOWSE_FENCE
+        FLOWSE_WMMA3(dB, b2, x) FLOWSE_WMMA3(dB, b2, y) FLOWSE_WMMA3(dB, b2, z) FLOWSE_WMMA3(dB, b2, w)
         FLOWSE_FENCE
         __syncthreads();     // next chunk's halo is complete; everyone has left this chunk's
     }
-#undef FLOWSE_WLOAD
+#undef FLOWSE_WLOADA
+#undef FLOWSE_WLOADB
 #undef FLOWSE_F4
 #undef FLOWSE_WXA
 #undef FLOWSE_WXB
