@@ -1143,7 +1143,7 @@ int launch_wino_weights(const float* w_packed, int Cout, int Cin, float* out, hi
 // wave (wn, ch) owns output channels 32 wn .. +31 and the component half ch (0: m0..m2 from d0..d4, 1: m3..m5 from
 // d1..d5) -- 3 x 16 accumulators per lane.  The two halves of A^T m are added in the epilogue's LDS tile.  fp32
 // error of the 1-D F(4,3) form is ~3x the direct sum's (6e-7 vs 2e-7 rel-L2 on unit-variance data).
-constexpr int F43_HROW = 18 * LDS_ROW + 24;   // words per halo pixel row: 4 rows = 0 mod 64 banks (quad 1 vs quad 0)
+constexpr int F43_HROW = 18 * LDS_ROW + 8;    // words per halo pixel row: 4 rows = 0 mod 64 banks (quad 1 vs quad 0)
 
 template <int GN, int CH>
 __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem) {
@@ -1167,16 +1167,15 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     const int m_tl = (b * H + y0) * W + x0;
 
     const int col4 = tid & 7, row0 = tid >> 3;
-    unsigned hvo1[H_LOADS], hvo2[H_LOADS];
-    int hlds[H_LOADS];                                   // LDS word offset of this thread's halo quads
-    unsigned hin = 0;
+    unsigned hpix[H_LOADS];                              // pixel offset of this thread's halo quads in the window
+    int hlds[H_LOADS];                                   // their LDS word offset (-1: past the last halo pixel)
+    unsigned hin = 0;                                    // bit q: quad q lies inside the image
 #pragma unroll
     for (int q = 0; q < H_LOADS; ++q) {
         const int hr = row0 + 32 * q;
         const int hy = hr / 18, hx = hr - hy * 18;
         const bool in = hr < HROWS && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
-        hvo1[q] = in ? (unsigned)((hy * W + hx) * C1 + col4 * 4) * 4u : OOB;
-        hvo2[q] = in ? (unsigned)((hy * W + hx) * C2 + col4 * 4) * 4u : OOB;
+        hpix[q] = (unsigned)(hy * W + hx);
         hlds[q] = hr < HROWS ? hy * F43_HROW + hx * LDS_ROW + col4 * 4 : -1;
         hin |= in ? (1u << q) : 0u;
     }
@@ -1189,33 +1188,41 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     const __amdgpu_buffer_rsrc_t rsrcw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wino), 0, a.Cout * 18 * Cin * 4, 0x00020000);
 
-    u32x4 rh[H_LOADS];
+    // The halo of the next chunk is staged in two halves of three quads (request -> GroupNorm/SiLU in registers ->
+    // LDS write into the idle buffer), so that only 12 staging registers are live at any time
+    u32x4 rh[3];
     float4 g_mu, g_sc, g_be;
 
-    auto gloadH = [&](int chunk) {
+    auto hload = [&](int chunk, int Q) -> u32x4 {
         const int c0 = chunk * KC;
         const bool second = c0 >= C1;
         const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * 4u;
-#pragma unroll
-        for (int q = 0; q < H_LOADS; ++q)
-            rh[q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, hvo2[q], soff, 0)
-                           : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, hvo1[q], soff, 0);
+        const unsigned cs = (unsigned)(second ? C2 : C1);
+        const unsigned off = ((hin >> Q) & 1u) ? (hpix[Q] * cs + (unsigned)col4 * 4u) * 4u : OOB;
+        return second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, soff, 0)
+                      : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, soff, 0);
+    };
+    auto gparams = [&](int chunk) {
         if (GN) {
-            const int cg = c0 + col4 * 4;
+            const int cg = chunk * KC + col4 * 4;
             g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
             g_sc = *reinterpret_cast<const float4*>(a.gn.scale + (int64_t)b * Cin + cg);
             g_be = *reinterpret_cast<const float4*>(a.gn.beta + cg);
         }
     };
-    auto xform1 = [&](int q) {
-        if (!GN) return;
-        rh[q] = gn_quad<GN>(rh[q], g_mu, g_sc, g_be, (hin >> q) & 1u);
+    auto gloadH = [&](int chunk, int h) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rh[q] = hload(chunk, 3 * h + q);
+        if (h == 0) gparams(chunk);
     };
-    auto lstoreH = [&](int buf) {
+    auto xform1 = [&](int Q) {
+        if (GN) rh[Q % 3] = gn_quad<GN>(rh[Q % 3], g_mu, g_sc, g_be, (hin >> Q) & 1u);
+    };
+    auto lstoreH = [&](int buf, int h) {
         float* Hb = Hs + buf * HBUF;
 #pragma unroll
-        for (int q = 0; q < H_LOADS; ++q)
-            if (hlds[q] >= 0) *reinterpret_cast<u32x4*>(Hb + hlds[q]) = rh[q];
+        for (int q = 0; q < 3; ++q)
+            if (hlds[3 * h + q] >= 0) *reinterpret_cast<u32x4*>(Hb + hlds[3 * h + q]) = rh[q];
     };
 
     const int lane = tid & 63;
@@ -1235,10 +1242,17 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-    gloadH(0);
+    {   // first chunk: all six quads at once (the accumulators are not live yet)
+        u32x4 t[H_LOADS];
 #pragma unroll
-    for (int q = 0; q < H_LOADS; ++q) xform1(q);
-    lstoreH(0);
+        for (int q = 0; q < H_LOADS; ++q) t[q] = hload(0, q);
+        gparams(0);
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            if (GN) t[q] = gn_quad<GN>(t[q], g_mu, g_sc, g_be, (hin >> q) & 1u);
+            if (hlds[q] >= 0) *reinterpret_cast<u32x4*>(Hs + hlds[q]) = t[q];
+        }
+    }
     __syncthreads();
 
 #define FLOWSE_FENCE __builtin_amdgcn_sched_barrier(0);
@@ -1264,76 +1278,71 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     //                                v4 = (d4 - d2) - 2 (d3 - d1) -> D[2]
 #define FLOWSE_WXA(D)                                                                                                \
     {                                                                                                                \
-        if (CH == 0) {                                                                                               \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
-                float* p0 = &D[0].x + e; const float d2 = (&D[2].x)[e], d4 = (&D[4].x)[e];                           \
-                *p0 = fmaf(4.f, *p0, fmaf(-5.f, d2, d4));                                                            \
-            }                                                                                                        \
-        } else {                                                                                                     \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
-                float* p0 = &D[0].x + e; const float d3 = (&D[2].x)[e], d5 = (&D[4].x)[e];                           \
-                *p0 = fmaf(4.f, *p0, fmaf(-5.f, d3, d5));                                                            \
-            }                                                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+            const float r0 = (&D[0].x)[e], r2 = (&D[2].x)[e], r4 = (&D[4].x)[e];                                     \
+            if (CH == 0) (&D[0].x)[e] = fmaf(4.f, r0, fmaf(-5.f, r2, r4));   /* v0 = 4 d0 - 5 d2 + d4 -> D[0] */      \
+            else (&D[4].x)[e] = fmaf(4.f, r0, fmaf(-5.f, r2, r4));           /* v5 = 4 d1 - 5 d3 + d5 -> D[4] */      \
         }                                                                                                            \
     }
 #define FLOWSE_WXB(D)                                                                                                \
     {                                                                                                                \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
-            const float r1 = (&D[1].x)[e], r2 = (&D[2].x)[e], r3 = (&D[3].x)[e], r4 = (&D[4].x)[e];                  \
+            const float r0 = (&D[0].x)[e], r1 = (&D[1].x)[e], r2 = (&D[2].x)[e], r3 = (&D[3].x)[e],                  \
+                        r4 = (&D[4].x)[e];                                                                           \
             if (CH == 0) { /* r1..r4 = d1..d4 */                                                                     \
                 (&D[1].x)[e] = fmaf(-4.f, r1 + r2, r3 + r4);                                                         \
                 (&D[2].x)[e] = fmaf(4.f, r1 - r2, r4 - r3);                                                          \
-            } else {       /* D[0..4] = d1..d5: r1 = d2, r2 = d3, r3 = d4; d1 was consumed by WXA -> use saved */    \
-                const float d1 = (&S.x)[e];                                                                          \
-                (&D[1].x)[e] = fmaf(2.f, r2 - d1, r3 - r1);                                                          \
-                (&D[2].x)[e] = fmaf(-2.f, r2 - d1, r3 - r1);                                                         \
+            } else {       /* r0..r3 = d1..d4 */                                                                     \
+                (&D[1].x)[e] = fmaf(2.f, r2 - r0, r3 - r1);                                                          \
+                (&D[2].x)[e] = fmaf(-2.f, r2 - r0, r3 - r1);                                                         \
             }                                                                                                        \
         }                                                                                                            \
     }
+    // operands: CH 0 -> D[0], D[1], D[2] = v0, v1, v2;  CH 1 -> D[4], D[1], D[2] = v5, v3, v4
 #define FLOWSE_WMMA3(V, BF, K)                                                                                       \
     _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                    \
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].K, BF[c].K, acc[c], 0, 0, 0);
-    // CH 1 needs d1 (= D[0] before WXA overwrites it) again in WXB: keep a copy
-#define FLOWSE_WSAVE(D) if (CH == 1) S = D[0];
-    // One k-block: request the next block's halo rows (one ahead, LDS) and the weights of the block after that (two
-    // ahead, L2 latency), run this block's 12 MFMAs with the next block's transform fenced in between
-#define FLOWSE_WPHASE(V, BF, NKX, NJ, DN, BKX, BJ, BCHK, BF2, XQ)                                                    \
-    FLOWSE_WLOADA(NKX, NJ, DN) FLOWSE_WLOADB(BKX, BJ, BCHK, BF2) FLOWSE_FENCE                                        \
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[(c == 0 && CH == 1) ? 4 : c].K, BF[c].K, acc[c], 0, 0, 0);
+    // One k-block: request the next block's operands (halo rows from LDS, weights from L2), run this block's 12
+    // MFMAs with the next block's transform (and one staged halo quad) fenced in between
+#define FLOWSE_WPHASE(V, BF, NKX, NJ, NCHK, DN, BFN, XQ)                                                             \
+    FLOWSE_WLOADA(NKX, NJ, DN) FLOWSE_WLOADB(NKX, NJ, NCHK, BFN) FLOWSE_FENCE                                        \
     FLOWSE_WMMA3(V, BF, x) FLOWSE_FENCE                                                                              \
     if (GN && (XQ) >= 0) xform1((XQ) < 0 ? 0 : (XQ));                                                                \
     FLOWSE_FENCE FLOWSE_WMMA3(V, BF, y) FLOWSE_FENCE                                                                 \
-    FLOWSE_WSAVE(DN) FLOWSE_WXA(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, z) FLOWSE_FENCE                                 \
+    FLOWSE_WXA(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, z) FLOWSE_FENCE                                                  \
     FLOWSE_WXB(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, w) FLOWSE_FENCE
 
-    float4 dA[5], dB[5], b0[3], b1[3], b2[3], S;
+    float4 dA[5], dB[5], bA[3], bB[3];
     {
         const int chunk = 0;
         (void)chunk;
-        FLOWSE_WLOADB(0, 0, 0, b0)
-        FLOWSE_WLOADB(0, 1, 0, b1)
+        FLOWSE_WLOADB(0, 0, 0, bA)
     }
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const float* Hcur = Hs + (chunk & 1) * HBUF;
-        const int cnext = min(chunk + 1, nchunks - 1);
-        gloadH(cnext);                                   // next chunk's halo: normalised on the way, stored late
+        const int cnext = min(chunk + 1, nchunks - 1), nbuf = (chunk + 1) & 1;
+        gloadH(cnext, 0);                                // next chunk's halo, first half
         FLOWSE_WLOADA(0, 0, dA)
-        FLOWSE_WSAVE(dA) FLOWSE_WXA(dA) FLOWSE_WXB(dA)
+        FLOWSE_WXA(dA) FLOWSE_WXB(dA)
         FLOWSE_FENCE
-        FLOWSE_WPHASE(dA, b0, 0, 1, dB, 0, 2, chunk, b2, -1)
-        FLOWSE_WPHASE(dB, b1, 0, 2, dA, 0, 3, chunk, b0, -1)
-        FLOWSE_WPHASE(dA, b2, 0, 3, dB, 1, 0, chunk, b1, -1)
-        FLOWSE_WPHASE(dB, b0, 1, 0, dA, 1, 1, chunk, b2, -1)
-        FLOWSE_WPHASE(dA, b1, 1, 1, dB, 1, 2, chunk, b0, 0)
-        FLOWSE_WPHASE(dB, b2, 1, 2, dA, 1, 3, chunk, b1, 1)
-        FLOWSE_WPHASE(dA, b0, 1, 3, dB, 2, 0, chunk, b2, 2)
-        FLOWSE_WPHASE(dB, b1, 2, 0, dA, 2, 1, chunk, b0, 3)
-        FLOWSE_WPHASE(dA, b2, 2, 1, dB, 2, 2, chunk, b1, 4)
-        FLOWSE_WPHASE(dB, b0, 2, 2, dA, 2, 3, chunk, b2, 5)
-        lstoreH((chunk + 1) & 1);                        // the other buffer: nobody reads it during this chunk
+        FLOWSE_WPHASE(dA, bA, 0, 1, chunk, dB, bB, -1)
+        FLOWSE_WPHASE(dB, bB, 0, 2, chunk, dA, bA, 0)
+        FLOWSE_WPHASE(dA, bA, 0, 3, chunk, dB, bB, 1)
+        FLOWSE_WPHASE(dB, bB, 1, 0, chunk, dA, bA, 2)
+        lstoreH(nbuf, 0);                                // the idle buffer: nobody reads it during this chunk
+        gloadH(cnext, 1);                                // second half
         FLOWSE_FENCE
-        FLOWSE_WPHASE(dA, b1, 2, 3, dB, 0, 0, cnext, b0, -1)
-        FLOWSE_WLOADB(0, 1, cnext, b1) FLOWSE_FENCE
-        FLOWSE_WMMA3(dB, b2, x) FLOWSE_WMMA3(dB, b2, y) FLOWSE_WMMA3(dB, b2, z) FLOWSE_WMMA3(dB, b2, w)
+        FLOWSE_WPHASE(dA, bA, 1, 1, chunk, dB, bB, -1)
+        FLOWSE_WPHASE(dB, bB, 1, 2, chunk, dA, bA, 3)
+        FLOWSE_WPHASE(dA, bA, 1, 3, chunk, dB, bB, 4)
+        FLOWSE_WPHASE(dB, bB, 2, 0, chunk, dA, bA, 5)
+        lstoreH(nbuf, 1);
+        FLOWSE_FENCE
+        FLOWSE_WPHASE(dA, bA, 2, 1, chunk, dB, bB, -1)
+        FLOWSE_WPHASE(dB, bB, 2, 2, chunk, dA, bA, -1)
+        FLOWSE_WPHASE(dA, bA, 2, 3, chunk, dB, bB, -1)
+        FLOWSE_WLOADB(0, 0, cnext, bA) FLOWSE_FENCE       // first weights of the next chunk
+        FLOWSE_WMMA3(dB, bB, x) FLOWSE_WMMA3(dB, bB, y) FLOWSE_WMMA3(dB, bB, z) FLOWSE_WMMA3(dB, bB, w)
         FLOWSE_FENCE
         __syncthreads();     // next chunk's halo is complete; everyone has left this chunk's
     }
@@ -1343,7 +1352,6 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
 #undef FLOWSE_WXA
 #undef FLOWSE_WXB
 #undef FLOWSE_WMMA3
-#undef FLOWSE_WSAVE
 #undef FLOWSE_WPHASE
 #undef FLOWSE_FENCE
 
@@ -1381,7 +1389,7 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
 }
 
 template <int GN>
-__global__ __launch_bounds__(256, 2) void conv3x3_f43_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv3x3_f43_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // waves 0,1: component half 0; waves 2,3: half 1.  Both bodies execute the same barriers.
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7)) conv3x3_f43_body<GN, 1>(a, smem);
