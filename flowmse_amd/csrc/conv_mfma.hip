@@ -1276,25 +1276,30 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     // CH 0 (rows d0..d4): v0 = 4 d0 - 5 d2 + d4, v1 = (d3 + d4) - 4 (d1 + d2), v2 = (d4 - d3) + 4 (d1 - d2)
     // CH 1 (rows d1..d5 as D[0..4]): v5 = 4 d1 - 5 d3 + d5 -> D[0];  v3 = (d4 - d2) + 2 (d3 - d1) -> D[1];
     //                                v4 = (d4 - d2) - 2 (d3 - d1) -> D[2]
+    // (float2 halves: hipcc emits the packed v_pk_add / v_pk_fma forms, half the VALU instructions)
+#define FLOWSE_H2(Q, H) (*reinterpret_cast<f32x2*>(&(Q).x + 2 * (H)))
 #define FLOWSE_WXA(D)                                                                                                \
     {                                                                                                                \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
-            const float r0 = (&D[0].x)[e], r2 = (&D[2].x)[e], r4 = (&D[4].x)[e];                                     \
-            if (CH == 0) (&D[0].x)[e] = fmaf(4.f, r0, fmaf(-5.f, r2, r4));   /* v0 = 4 d0 - 5 d2 + d4 -> D[0] */      \
-            else (&D[4].x)[e] = fmaf(4.f, r0, fmaf(-5.f, r2, r4));           /* v5 = 4 d1 - 5 d3 + d5 -> D[4] */      \
+        const f32x2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f};                                                             \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                              \
+            const f32x2 r0 = FLOWSE_H2(D[0], h), r2 = FLOWSE_H2(D[2], h), r4 = FLOWSE_H2(D[4], h);                   \
+            const f32x2 v = __builtin_elementwise_fma(c4, r0, __builtin_elementwise_fma(cm5, r2, r4));               \
+            if (CH == 0) FLOWSE_H2(D[0], h) = v;   /* v0 = 4 d0 - 5 d2 + d4 -> D[0] */                                \
+            else FLOWSE_H2(D[4], h) = v;           /* v5 = 4 d1 - 5 d3 + d5 -> D[4] */                                \
         }                                                                                                            \
     }
 #define FLOWSE_WXB(D)                                                                                                \
     {                                                                                                                \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
-            const float r0 = (&D[0].x)[e], r1 = (&D[1].x)[e], r2 = (&D[2].x)[e], r3 = (&D[3].x)[e],                  \
-                        r4 = (&D[4].x)[e];                                                                           \
+        const f32x2 c4 = {4.f, 4.f}, cm4 = {-4.f, -4.f}, c2 = {2.f, 2.f}, cm2 = {-2.f, -2.f};                        \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                              \
+            const f32x2 r0 = FLOWSE_H2(D[0], h), r1 = FLOWSE_H2(D[1], h), r2 = FLOWSE_H2(D[2], h),                   \
+                        r3 = FLOWSE_H2(D[3], h), r4 = FLOWSE_H2(D[4], h);                                            \
             if (CH == 0) { /* r1..r4 = d1..d4 */                                                                     \
-                (&D[1].x)[e] = fmaf(-4.f, r1 + r2, r3 + r4);                                                         \
-                (&D[2].x)[e] = fmaf(4.f, r1 - r2, r4 - r3);                                                          \
+                FLOWSE_H2(D[1], h) = __builtin_elementwise_fma(cm4, r1 + r2, r3 + r4);                               \
+                FLOWSE_H2(D[2], h) = __builtin_elementwise_fma(c4, r1 - r2, r4 - r3);                                \
             } else {       /* r0..r3 = d1..d4 */                                                                     \
-                (&D[1].x)[e] = fmaf(2.f, r2 - r0, r3 - r1);                                                          \
-                (&D[2].x)[e] = fmaf(-2.f, r2 - r0, r3 - r1);                                                         \
+                FLOWSE_H2(D[1], h) = __builtin_elementwise_fma(c2, r2 - r0, r3 - r1);                                \
+                FLOWSE_H2(D[2], h) = __builtin_elementwise_fma(cm2, r2 - r0, r3 - r1);                               \
             }                                                                                                        \
         }                                                                                                            \
     }
@@ -1349,6 +1354,7 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
 #undef FLOWSE_WLOADA
 #undef FLOWSE_WLOADB
 #undef FLOWSE_F4
+#undef FLOWSE_H2
 #undef FLOWSE_WXA
 #undef FLOWSE_WXB
 #undef FLOWSE_WMMA3
