@@ -837,12 +837,19 @@ int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps) {
     return (HW % 128) == 0 ? HW / 128 : 0;
 }
 
+static const bool g_no_wino_policy = getenv("FLOWSE_NO_WINOGRAD") != nullptr || getenv("FLOWSE_NO_HALO_CONV") != nullptr ||
+                                     getenv("FLOWSE_FORCE_GENERIC_CONV") != nullptr;
+
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     const int64_t M = (int64_t)B * H * W;
     const int bn = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;       // N tile launch_conv picks for this width
     const int64_t tiles = ((M + 127) / 128) * ((Cout + bn - 1) / bn);
     const int steps = ((Cin + KC - 1) / KC) * taps;
     if (tiles >= 256 || steps < 8) return 1;          // measured: 256 beats 128 and 64 at B = 1..8
+    // the Winograd halo kernels tile N by 64: one block per CU is already better than slicing K
+    if (taps == 9 && !(H & 7) && !(W & 15) && (Cin % KC) == 0 && (Cout % 64) == 0 && !g_no_wino_policy &&
+        (M / 128) * (Cout / 64) >= 256)
+        return 1;
     int64_t want = (512 + tiles - 1) / tiles;
     int64_t maxs = steps / 4;
     int64_t ks = want < maxs ? want : maxs;

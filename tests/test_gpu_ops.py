@@ -67,7 +67,7 @@ SPLITK_CASES = [
     (8, 8, 8, 256, 0, 256, 3, True, False, False, 1.0),
     (2, 16, 16, 512, 0, 256, 1, True, False, True, 1.0),         # 1x1 shortcut on concat width
     (3, 6, 6, 128, 64, 192, 3, False, True, False, 1.0),         # ragged: M, K, N all off the tile grid
-    (8, 32, 32, 256, 0, 256, 3, True, True, True, 0.70710678),
+    (4, 32, 32, 256, 0, 256, 3, True, True, True, 0.70710678),    # B = 8 would take the Winograd kernel instead
 ]
 
 
@@ -142,6 +142,7 @@ WINO_CASES = [
     (4, 64, 64, 128, 128, 256, False, True, 1.0, True),
     (1, 128, 144, 32, 0, 192, False, False, 1.0, False),      # W = 9 tiles, three 64-wide N tiles
     (1, 256, 128, 64, 0, 64, False, True, 1.0, True),
+    (8, 32, 32, 256, 256, 256, True, True, 0.70710678, True),   # one block per CU: preferred over split-K
 ]
 
 
