@@ -217,18 +217,23 @@ def main():
                 if k:
                     traffic = tj["kernels"][k]["hbm_bytes_per_launch"]
                     traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes)"
-            winograd = args.precision == "fp32" and not os.environ.get("FLOWSE_NO_WINOGRAD")
-            kname = ("flowse::conv3x3_wino_kernel<2> (fp32 F(2,3)-Winograd implicit-GEMM 3x3 conv, 8x16 pixel x 64 "
-                     "channel tile, LDS halo, fused GroupNorm+SiLU input)" if winograd else
+            form = None
+            if args.precision == "fp32" and not os.environ.get("FLOWSE_NO_WINOGRAD"):
+                form = "F(2,3)" if os.environ.get("FLOWSE_WINOGRAD") == "f23" else "F(4,3)"
+            kname = ({"F(4,3)": "flowse::conv3x3_f43_kernel<2>", "F(2,3)": "flowse::conv3x3_wino_kernel<2>"}[form] +
+                     f" (fp32 {form}-Winograd implicit-GEMM 3x3 conv, 8x16 pixel x 64 channel tile, LDS halo, fused "
+                     "GroupNorm+SiLU input, weights streamed from L2 in MFMA fragment order)" if form else
                      "flowse::conv3x3_halo_kernel<2,2,2,2,2> (fp32 implicit-GEMM 3x3 conv, 128x128 tile, LDS halo, "
                      "fused GroupNorm+SiLU input)" if args.precision == "fp32" else
                      "flowse::conv3x3_halo_bf16_kernel (16-bit operand variant of the halo kernel)")
-            issued = ach * (2.0 / 3.0 if winograd else 1.0)
+            issue = {"F(4,3)": 0.5, "F(2,3)": 2.0 / 3.0, None: 1.0}[form]
+            issued = ach * issue
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_FP32_MATRIX_TFLOPS,
                                "achieved_definition": "algorithmic direct-convolution FLOPs (SURVEY 8d) / launch time"
-                                                      + ("; F(2,3) issues 2/3 of them on the matrix cores" if winograd else ""),
+                                                      + (f"; {form} Winograd issues {issue:.3g} of them on the matrix "
+                                                         "cores (mfma_issued)" if form else ""),
                                "mfma_issued": issued, "mfma_issued_frac": issued / PEAK_FP32_MATRIX_TFLOPS,
                                "traffic": traffic, "traffic_source": traffic_src,
                                "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
