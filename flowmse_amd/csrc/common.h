@@ -141,6 +141,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce = true);
 int launch_splitk_reduce(const ConvArgs& a, hipStream_t s);
 // number of K slices launch_conv will use for this shape (1 = no split) and the partial-buffer size in floats
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps);
+// true when the 4-channel input conv runs on the matrix cores (then it also emits fused GroupNorm statistics,
+// H*W/128 partial blocks per sample)
+bool conv_cin4_uses_mfma(int B, int H, int W, int Cout, int taps);
 
 // direct conv for 4 input channels (input layer, Combine): VALU, HBM-bound
 int launch_conv_cin4(const ConvArgs& a, hipStream_t s);

@@ -1961,8 +1961,73 @@ __global__ __launch_bounds__(256) void conv_cin4_kernel(ConvArgs a, int Q) {
         make_float4(o[0] * a.scale, o[1] * a.scale, o[2] * a.scale, o[3] * a.scale);
 }
 
+// Matrix-core form of the 4 -> 128 input convolution for full-size images: K = 9 taps x 4 channels = 36 (+4 zero),
+// a lane's A operand is simply the float4 of one neighbouring pixel (taps 2q for lanes 0-31, 2q+1 for lanes 32-63),
+// read straight from global memory; the whole 128 x 40 weight matrix sits in registers.  Block = 128 flat pixels x 128
+// channels, wave = 32 pixels x 128 channels (4 accumulator tiles); output-write bound.  Shares the standard epilogue,
+// i.e. also emits the GroupNorm partial statistics of its output.
+__global__ __launch_bounds__(256, 2) void conv3x3_cin4_mfma_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int M = a.B * HW;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.x * 128;
+    const int m = m0 + wave * 32 + li;                  // this lane's pixel (A row)
+    const int rem = m % HW;
+    const int y = rem / W, x = rem - y * W;
+    float4 af[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int t = 2 * q + kh;                        // tap 9 does not exist: zero operand
+        const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+        const bool ok = t < 9 && m < M && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+        const float4 v = *reinterpret_cast<const float4*>(a.in1 + (int64_t)(ok ? m + dy * W + dx : 0) * 4);
+        af[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x16 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = j * 32 + li;                       // B row = output channel (Cout == 128)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int t = 2 * q + kh;
+            const float4 w4 = t < 9 ? *reinterpret_cast<const float4*>(a.w + ((int64_t)n * 9 + t) * 4)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, w4.x, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, w4.y, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, w4.z, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, w4.w, acc[0][j], 0, 0, 0);
+        }
+    }
+    conv_epilogue<4, 1, 1, 4>(a, acc, smem, m0, 0, M, HW, 0);
+}
+
+bool conv_cin4_uses_mfma(int B, int H, int W, int Cout, int taps) {
+    static const bool off = getenv("FLOWSE_NO_CIN4_MFMA") != nullptr;      // test / A-B hook
+    return !off && taps == 9 && Cout == 128 && ((H * W) % 128) == 0 && (int64_t)B * H * W >= 128 * 256 && !g_force_generic;
+}
+
 int launch_conv_cin4(const ConvArgs& a, hipStream_t s) {
     const int Q = a.Cout / 4;
+    if (a.C1 == 4 && a.C2 == 0 && a.ksplit <= 1 && !a.gn.mean && conv_cin4_uses_mfma(a.B, a.H, a.W, a.Cout, a.taps)) {
+        const size_t lds = ((size_t)128 * (128 + 4) + 256 * 8) * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_cin4_mfma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
+        const int grid = (int)((int64_t)a.B * a.H * a.W / 128);
+        hipLaunchKernelGGL(conv3x3_cin4_mfma_kernel, dim3(grid), dim3(256), lds, s, a);
+        FLOWSE_LAUNCH_CHECK();
+        return OK;
+    }
     if (a.C1 != 4 || a.C2 != 0 || (a.Cout & 3) || Q > 256 || (256 % Q) != 0 ||
         (size_t)a.Cout * a.taps * 16 > 64 * 1024) {
         return launch_conv(a, s);      // generic path handles any shape

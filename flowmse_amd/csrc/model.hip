@@ -559,7 +559,8 @@ struct Builder {
         const size_t a_off = a.off, b_off = b2 ? b2->off : 0, o_off = o.off, r_off = res ? res->off : 0;
         const bool has2 = b2 != nullptr, hasres = res != nullptr;
         const int ks = cin4 ? 1 : conv_ksplit(Bn, H, Wd, C1 + C2, Cout, taps);
-        const int st_nblk = (cin4 || out_is_res || Cout < 16) ? 0 : conv_fused_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps);
+        int st_nblk = (cin4 || out_is_res || Cout < 16) ? 0 : conv_fused_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps);
+        if (cin4 && !out_is_res && C1 == 4 && !has2 && conv_cin4_uses_mfma(Bn, H, Wd, Cout, taps)) st_nblk = H * Wd / 128;
         if (st_nblk > 0) {
             o.st_nblk = st_nblk;
             o.st_off = arena.alloc((size_t)Bn * st_nblk * Cout * 2 * sizeof(float));

@@ -39,6 +39,8 @@ CONV_CASES = [
     (2, 16, 8, 4, 0, 32, 1, True, False, True, 1.0),           # Combine (direct kernel, residual)
     (1, 64, 64, 128, 0, 128, 3, True, True, True, 0.70710678),  # several M tiles
     (1, 2, 2, 512, 0, 256, 3, True, False, False, 1.0),        # deep K, tiny image
+    (2, 128, 144, 4, 0, 128, 3, True, False, False, 1.0),      # input layer on the matrix cores (>= 256 blocks)
+    (1, 256, 128, 4, 0, 128, 3, True, True, True, 0.5),
 ]
 
 
