@@ -160,6 +160,10 @@ int launch_gn_finalize(const float* partial1, int nblk1, int C1, const float* pa
                        int HW, int G, const float* gamma, float eps, float* mean /*[B][C]*/,
                        float* scale /*[B][C]*/, hipStream_t s);
 
+// finalize + apply in one launch (small images: HW * C / G elements per block)
+int launch_gn_finalize_apply(const float* in1, const float* partial1, int nblk1, int C1, const float* in2,
+                             const float* partial2, int nblk2, int C2, int B, int HW, int G, const float* gamma,
+                             const float* beta, float eps, int silu, float* out, hipStream_t s);
 int launch_gn_apply(const float* in1, int C1, const float* in2, int C2, int B, int HW,
                     GnParams gn, int silu, float* out, hipStream_t s);
 

@@ -532,6 +532,53 @@ struct Builder {
             if (temp[k]) arena.release(poff[k]);
         return g;
     }
+    // GroupNorm (+ SiLU) materialised into a new tensor.  Small images: statistics finalize and the apply pass are ONE
+    // launch (a block per (group, sample) reduces the partials and normalises its HW x C/G elements); otherwise
+    // finalize + float4 apply.
+    Tn gn_norm(const Tn& a, const Tn* b2, int64_t w_gamma, int64_t w_beta, bool silu) {
+        const int C1 = a.C, C2 = b2 ? b2->C : 0, C = C1 + C2, HW = a.H * a.W, Bn = B;
+        const int G = std::min(C / 4, 32);
+        if ((int64_t)HW * (C / G) > 8192) {
+            GnBuf g = gn(a, b2, w_gamma, w_beta);
+            Tn o = gn_apply(a, b2, g, silu);
+            gn_release(g);
+            return o;
+        }
+        flowse_model* M = m;
+        size_t poff[2] = {0, 0};
+        int pnblk[2] = {0, 0};
+        bool temp[2] = {false, false};
+        const Tn* src[2] = {&a, b2};
+        for (int k = 0; k < 2; ++k) {
+            if (!src[k]) continue;
+            if (src[k]->st_nblk > 0) {
+                poff[k] = src[k]->st_off;
+                pnblk[k] = src[k]->st_nblk;
+                continue;
+            }
+            const int Ck = src[k]->C;
+            const int nblk = gn_partial_blocks(HW, Ck);
+            poff[k] = arena.alloc((size_t)Bn * nblk * Ck * 2 * sizeof(float));
+            pnblk[k] = nblk;
+            temp[k] = true;
+            const size_t t_off = src[k]->off, p_off = poff[k];
+            op("gn_stats@" + std::to_string(src[k]->H) + "x" + std::to_string(src[k]->W), [=](hipStream_t s) {
+                return launch_gn_stats(M->A(t_off), Ck, nullptr, 0, Bn, HW, M->A(p_off), nblk, s);
+            }, 3.0 * Bn * HW * Ck, 4.0 * Bn * HW * Ck);
+        }
+        Tn o = alloc(a.H, a.W, C);
+        const size_t a_off = a.off, b_off = b2 ? b2->off : 0, o_off = o.off, p0 = poff[0], p1 = poff[1];
+        const int n0 = pnblk[0], n1 = pnblk[1];
+        const bool has2 = b2 != nullptr;
+        op("gn_norm@" + std::to_string(a.H) + "x" + std::to_string(a.W), [=](hipStream_t s) {
+            return launch_gn_finalize_apply(M->A(a_off), M->A(p0), n0, C1, has2 ? M->A(b_off) : nullptr,
+                                            has2 ? M->A(p1) : nullptr, n1, C2, Bn, HW, G, M->W(w_gamma), M->W(w_beta),
+                                            1e-6f, silu ? 1 : 0, M->A(o_off), s);
+        }, 8.0 * Bn * HW * C, 8.0 * Bn * HW * C);
+        for (int k = 0; k < 2; ++k)
+            if (temp[k]) arena.release(poff[k]);
+        return o;
+    }
     void gn_release(const GnBuf& g) {
         arena.release(g.mean);
         arena.release(g.scale);
@@ -649,22 +696,22 @@ struct Builder {
     // ResnetBlockBigGANpp.forward, layerspp.py:245-274
     Tn resblock(const Module& mod, const Tn& x1, const Tn* x2) {
         const float rs2 = 0.70710678118654752440f;
-        GnBuf g0 = gn(x1, x2, mod.w_gn0_g, mod.w_gn0_b);
         Tn h1, xs;
         if (!mod.up && !mod.down) {
             if (conv_supports_fused_gn(B, x1.H, x1.W, x1.C, x2 ? x2->C : 0, mod.out_ch, 9)) {
                 // Conv_0(act(GroupNorm_0(x))) in one kernel: the normalised tensor never reaches HBM
+                GnBuf g0 = gn(x1, x2, mod.w_gn0_g, mod.w_gn0_b);
                 h1 = conv("conv0_3x3_gn", x1, x2, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f, false,
                           false, &g0, true, mod.wq_c0);
                 gn_release(g0);
             } else {
-                Tn h0 = gn_apply(x1, x2, g0, true);
-                gn_release(g0);
+                Tn h0 = gn_norm(x1, x2, mod.w_gn0_g, mod.w_gn0_b, true);
                 h1 = conv("conv0_3x3", h0, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f);
                 release(h0);
             }
             if (mod.shortcut) xs = conv("conv2_1x1", x1, x2, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f);
         } else {
+            GnBuf g0 = gn(x1, x2, mod.w_gn0_g, mod.w_gn0_b);
             Tn hr = fir(x1, mod.up, &g0, true, nullptr);
             Tn xr = fir(x1, mod.up, nullptr, false, nullptr);
             gn_release(g0);
@@ -674,16 +721,15 @@ struct Builder {
             xs = conv("conv2_1x1", xr, nullptr, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f);
             release(xr);
         }
-        GnBuf g1 = gn(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b);
         Tn out;
         if (conv_supports_fused_gn(B, h1.H, h1.W, h1.C, 0, mod.out_ch, 9)) {
+            GnBuf g1 = gn(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b);
             out = conv("conv1_3x3_gn", h1, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, xs.valid() ? &xs : &x1, rs2,
                        false, false, &g1, true, mod.wq_c1);
             gn_release(g1);
             release(h1);
         } else {
-            Tn h2 = gn_apply(h1, nullptr, g1, true);
-            gn_release(g1);
+            Tn h2 = gn_norm(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b, true);
             release(h1);
             out = conv("conv1_3x3", h2, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, xs.valid() ? &xs : &x1, rs2);
             release(h2);
@@ -697,9 +743,7 @@ struct Builder {
         flowse_model* M = m;
         const float rs2 = 0.70710678118654752440f;
         const int C = x.C, L = x.H * x.W, Bn = B;
-        GnBuf g = gn(x, nullptr, mod.w_gn0_g, mod.w_gn0_b);
-        Tn hn = gn_apply(x, nullptr, g, false);
-        gn_release(g);
+        Tn hn = gn_norm(x, nullptr, mod.w_gn0_g, mod.w_gn0_b, false);
         Tn qkv = conv("attn_qkv", hn, nullptr, mod.w_qkv, mod.w_qkv_b, -1, 3 * C, 1, nullptr, 1.f);
         release(hn);
         Tn o = alloc(x.H, x.W, C);
@@ -817,9 +861,10 @@ static int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
         }
         const Module& gnm = next();
         const Module& pcv = next();
-        GnBuf g = bd.gn(h, nullptr, gnm.w_a, gnm.w_a_b);
         const bool pfuse = conv_supports_fused_gn(B, h.H, h.W, h.C, 0, 4, 9);
-        Tn ph = pfuse ? h : bd.gn_apply(h, nullptr, g, true);
+        GnBuf g;
+        if (pfuse) g = bd.gn(h, nullptr, gnm.w_a, gnm.w_a_b);
+        Tn ph = pfuse ? h : bd.gn_norm(h, nullptr, gnm.w_a, gnm.w_a_b, true);
         const GnBuf* pg = pfuse ? &g : nullptr;
         if (!pyr.valid()) {
             pyr = bd.conv("pyramid_conv", ph, nullptr, pcv.w_a, pcv.w_a_b, -1, 4, 9, nullptr, 1.f, false, false, pg, true);
@@ -828,7 +873,7 @@ static int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
             bd.release(pyr);
             pyr = bd.conv("pyramid_conv", ph, nullptr, pcv.w_a, pcv.w_a_b, -1, 4, 9, &up, 1.f, true, false, pg, true);
         }
-        bd.gn_release(g);
+        if (pfuse) bd.gn_release(g);
         if (!pfuse) bd.release(ph);
         if (lv != 0) {
             Tn h2 = bd.resblock(next(), h, nullptr);

@@ -72,16 +72,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __res
 
 // grid (G, B), 256 threads.  Channels [0,C1) take their partials from set 1 (ppb1 pixels per block), [C1,C1+C2) from
 // set 2.  Blocks and channels are merged with Chan's formula in fp64: mean and biased variance of the group.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ p1, int nblk1, int ppb1, int C1,
-                                                         const float* __restrict__ p2, int nblk2, int ppb2, int C2,
-                                                         int HW, int G, const float* __restrict__ gamma, float eps,
-                                                         float* __restrict__ mean, float* __restrict__ scale) {
+// (mean, 1/sqrt(var + eps)) of group g of sample b from the per-(block, channel) partials; all 256 threads of the
+// block take part and receive the result.  Two passes, both plain fp64 sums (no divisions in the loops):
+//   mean = sum n_i mean_i / N ;  var = sum (M2_i + n_i (mean_i - mean)^2) / N      (N = HW * cpg)
+__device__ __forceinline__ void gn_group_stats(const float* __restrict__ p1, int nblk1, int ppb1, int C1,
+                                               const float* __restrict__ p2, int nblk2, int ppb2, int C2, int HW,
+                                               int G, float eps, int g, int b, float& mean_out, float& rstd_out) {
     __shared__ double wsum[4];
-    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;       // "lane" = thread 0..255 here
+    const int lane = threadIdx.x;                                       // "lane" = thread 0..255 here
     const int C = C1 + C2;
     const int cpg = C / G;
-    // Two passes over the (block, channel) partials of the group, both plain fp64 sums (no divisions in the loops):
-    //   mean = sum n_i mean_i / N ;  var = sum (M2_i + n_i (mean_i - mean)^2) / N      (N = HW * cpg)
     double s1 = 0.0;
     for (int j = 0; j < cpg; ++j) {
         const int c = g * cpg + j;
@@ -119,8 +119,20 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     __syncthreads();
     s2 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     const double var = s2 / N;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float muf = (float)mu;
+    rstd_out = (float)(1.0 / sqrt(var + (double)eps));
+    mean_out = (float)mu;
+}
+
+// grid (G, B), 256 threads.  Channels [0,C1) take their partials from set 1 (ppb1 pixels per block), [C1,C1+C2) from
+// set 2.  Blocks and channels are merged with Chan's formula in fp64: mean and biased variance of the group.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ p1, int nblk1, int ppb1, int C1,
+                                                         const float* __restrict__ p2, int nblk2, int ppb2, int C2,
+                                                         int HW, int G, const float* __restrict__ gamma, float eps,
+                                                         float* __restrict__ mean, float* __restrict__ scale) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int C = C1 + C2, cpg = C / G;
+    float muf, rstd;
+    gn_group_stats(p1, nblk1, ppb1, C1, p2, nblk2, ppb2, C2, HW, G, eps, g, b, muf, rstd);
     if (lane < cpg) {
         const int c = g * cpg + lane;
         mean[(int64_t)b * C + c] = muf;
@@ -155,6 +167,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     *reinterpret_cast<float4*>(out + pix * C + c) = o;
 }
 
+// Small images: finalize and apply in ONE launch.  grid (G, B): the block reduces its group's partials exactly like
+// gn_finalize, then normalises (+ SiLU) the group's HW x cpg elements of cat[in1, in2] into `out`.
+__global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const float* __restrict__ in1, const float* __restrict__ p1,
+                                                               int nblk1, int ppb1, int C1,
+                                                               const float* __restrict__ in2, const float* __restrict__ p2,
+                                                               int nblk2, int ppb2, int C2, int HW, int G,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, int silu,
+                                                               float* __restrict__ out) {
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int C = C1 + C2, cpg = C / G;
+    float muf, rstd;
+    gn_group_stats(p1, nblk1, ppb1, C1, p2, nblk2, ppb2, C2, HW, G, eps, g, b, muf, rstd);
+    const int n = HW * cpg;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int pix = i / cpg, c = g * cpg + (i - pix * cpg);
+        const int64_t px = (int64_t)b * HW + pix;
+        const float x = c < C1 ? in1[px * C1 + c] : in2[px * C2 + (c - C1)];
+        float v = fmaf(x - muf, rstd * gamma[c], beta[c]);
+        if (silu) v = silu_f(v);
+        out[px * C + c] = v;
+    }
+}
+
 int launch_gn_stats(const float* in1, int C1, const float* in2, int C2, int B, int HW, float* partial, int nblk,
                     hipStream_t s) {
     const int C = C1 + C2;
@@ -179,6 +215,21 @@ int launch_gn_finalize(const float* partial1, int nblk1, int C1, const float* pa
     }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, s, partial1, nblk1, ppb1, C1, partial2, nblk2, ppb2,
                        C2, HW, G, gamma, eps, mean, scale);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+int launch_gn_finalize_apply(const float* in1, const float* partial1, int nblk1, int C1, const float* in2,
+                             const float* partial2, int nblk2, int C2, int B, int HW, int G, const float* gamma,
+                             const float* beta, float eps, int silu, float* out, hipStream_t s) {
+    const int ppb1 = gn_pixels_per_block(HW, nblk1), ppb2 = nblk2 > 0 ? gn_pixels_per_block(HW, nblk2) : 1;
+    const int C = C1 + C2;
+    if (C % G != 0 || (C2 > 0 && (!partial2 || !in2))) {
+        set_error("gn_finalize_apply: unsupported C=%d G=%d", C, G);
+        return ERR_SHAPE;
+    }
+    hipLaunchKernelGGL(gn_finalize_apply_kernel, dim3(G, B), dim3(256), 0, s, in1, partial1, nblk1, ppb1, C1, in2, partial2,
+                       nblk2, ppb2, C2, HW, G, gamma, beta, eps, silu, out);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
