@@ -170,10 +170,11 @@ int launch_gn_apply(const float* in1, int C1, const float* in2, int C2, int B, i
 // ------------------------------------------------------------------ FIR resampling ([1,3,3,1] x [1,3,3,1] / 64)
 // down: out[B][H/2][W/2][C]; up: out[B][2H][2W][C] (gain 4).  Optional fused GN(+SiLU) on the input
 // (gn.mean == null -> raw), optional elementwise `add` tensor (same shape as out) summed into the result.
+// out2 (optional): the same resampling of the raw (un-normalised) input, written from the same read.
 int launch_fir_down(const float* in, int B, int H, int W, int C, GnParams gn, int silu, float* out,
-                    hipStream_t s);
+                    hipStream_t s, float* out2 = nullptr);
 int launch_fir_up(const float* in, int B, int H, int W, int C, GnParams gn, int silu, const float* add,
-                  float* out, hipStream_t s);
+                  float* out, hipStream_t s, float* out2 = nullptr);
 // generic NCHW upfirdn2d (drop-in for the reference's op/upfirdn2d ABI), kernel up to 8x8
 int launch_upfirdn2d_nchw(const float* in, const float* kernel, int planes, int in_h, int in_w, int kh,
                           int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,

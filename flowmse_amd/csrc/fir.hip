@@ -23,8 +23,7 @@ struct GnQuad {
     int on, silu;
 };
 
-__device__ __forceinline__ float4 load_tx(const float* p, const GnQuad& g) {
-    float4 v = *reinterpret_cast<const float4*>(p);
+__device__ __forceinline__ float4 apply_tx(float4 v, const GnQuad& g) {
     if (g.on) {
         v.x = fmaf(v.x - g.mu.x, g.sc.x, g.be.x);
         v.y = fmaf(v.y - g.mu.y, g.sc.y, g.be.y);
@@ -48,8 +47,10 @@ __device__ __forceinline__ GnQuad gn_quad(const GnParams& gn, int silu, int b, i
 }
 
 // grid: (ceil(OW * C/4 / 256), OH, B); one thread = one output pixel x one channel quad (32-bit index math only)
+// out2 (optional): the same resampling of the RAW input (the ResnetBlock's shortcut branch resamples x while the
+// main branch resamples act(GroupNorm(x)), layerspp.py:251-259): both from one read of the input
 __global__ __launch_bounds__(256) void fir_down_kernel(const float* __restrict__ in, int H, int W, int C, GnParams gn,
-                                                       int silu, float* __restrict__ out) {
+                                                       int silu, float* __restrict__ out, float* __restrict__ out2) {
     const unsigned Q = C >> 2, OW = W >> 1, OH = H >> 1;
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= OW * Q) return;
@@ -59,31 +60,42 @@ __global__ __launch_bounds__(256) void fir_down_kernel(const float* __restrict__
     const float k1[4] = {1.f, 3.f, 3.f, 1.f};
     const GnQuad g = gn_quad(gn, silu, b, C, c);
     const float* base = in + (int64_t)b * H * W * C + c;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
 #pragma unroll
     for (int ty = 0; ty < 4; ++ty) {
         const int y = 2 * oy - 1 + ty;
         if ((unsigned)y >= (unsigned)H) continue;
-        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 row = make_float4(0.f, 0.f, 0.f, 0.f), row2 = row;
 #pragma unroll
         for (int tx = 0; tx < 4; ++tx) {
             const int x = 2 * (int)ox - 1 + tx;
             if ((unsigned)x >= (unsigned)W) continue;
-            const float4 v = load_tx(base + ((int64_t)y * W + x) * C, g);
+            const float4 r = *reinterpret_cast<const float4*>(base + ((int64_t)y * W + x) * C);
+            const float4 v = apply_tx(r, g);
             row.x = fmaf(k1[tx], v.x, row.x); row.y = fmaf(k1[tx], v.y, row.y);
             row.z = fmaf(k1[tx], v.z, row.z); row.w = fmaf(k1[tx], v.w, row.w);
+            if (out2) {
+                row2.x = fmaf(k1[tx], r.x, row2.x); row2.y = fmaf(k1[tx], r.y, row2.y);
+                row2.z = fmaf(k1[tx], r.z, row2.z); row2.w = fmaf(k1[tx], r.w, row2.w);
+            }
         }
         acc.x = fmaf(k1[ty], row.x, acc.x); acc.y = fmaf(k1[ty], row.y, acc.y);
         acc.z = fmaf(k1[ty], row.z, acc.z); acc.w = fmaf(k1[ty], row.w, acc.w);
+        if (out2) {
+            acc2.x = fmaf(k1[ty], row2.x, acc2.x); acc2.y = fmaf(k1[ty], row2.y, acc2.y);
+            acc2.z = fmaf(k1[ty], row2.z, acc2.z); acc2.w = fmaf(k1[ty], row2.w, acc2.w);
+        }
     }
     const float s = 1.f / 64.f;
-    float* o = out + (((int64_t)b * OH + oy) * OW + ox) * C + c;
-    *reinterpret_cast<float4*>(o) = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
+    const int64_t off = (((int64_t)b * OH + oy) * OW + ox) * C + c;
+    *reinterpret_cast<float4*>(out + off) = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
+    if (out2) *reinterpret_cast<float4*>(out2 + off) = make_float4(acc2.x * s, acc2.y * s, acc2.z * s, acc2.w * s);
 }
 
 // grid: (ceil(2W * C/4 / 256), 2H, B)
 __global__ __launch_bounds__(256) void fir_up_kernel(const float* __restrict__ in, int H, int W, int C, GnParams gn,
-                                                     int silu, const float* __restrict__ add, float* __restrict__ out) {
+                                                     int silu, const float* __restrict__ add, float* __restrict__ out,
+                                                     float* __restrict__ out2) {
     const unsigned Q = C >> 2, OW = W * 2, OH = H * 2;
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= OW * Q) return;
@@ -97,24 +109,33 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const float* __restrict__ i
     const int y0 = (oy & 1) ? ay : ay - 1, x0 = (ox & 1) ? ax : ax - 1;
     const float wy0 = (oy & 1) ? 3.f : 1.f, wy1 = (oy & 1) ? 1.f : 3.f;
     const float wx0 = (ox & 1) ? 3.f : 1.f, wx1 = (ox & 1) ? 1.f : 3.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
 #pragma unroll
     for (int ty = 0; ty < 2; ++ty) {
         const int y = y0 + ty;
         if ((unsigned)y >= (unsigned)H) continue;
         const float wy = ty ? wy1 : wy0;
-        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 row = make_float4(0.f, 0.f, 0.f, 0.f), row2 = row;
 #pragma unroll
         for (int tx = 0; tx < 2; ++tx) {
             const int x = x0 + tx;
             if ((unsigned)x >= (unsigned)W) continue;
             const float wx = tx ? wx1 : wx0;
-            const float4 v = load_tx(base + ((int64_t)y * W + x) * C, g);
+            const float4 r = *reinterpret_cast<const float4*>(base + ((int64_t)y * W + x) * C);
+            const float4 v = apply_tx(r, g);
             row.x = fmaf(wx, v.x, row.x); row.y = fmaf(wx, v.y, row.y);
             row.z = fmaf(wx, v.z, row.z); row.w = fmaf(wx, v.w, row.w);
+            if (out2) {
+                row2.x = fmaf(wx, r.x, row2.x); row2.y = fmaf(wx, r.y, row2.y);
+                row2.z = fmaf(wx, r.z, row2.z); row2.w = fmaf(wx, r.w, row2.w);
+            }
         }
         acc.x = fmaf(wy, row.x, acc.x); acc.y = fmaf(wy, row.y, acc.y);
         acc.z = fmaf(wy, row.z, acc.z); acc.w = fmaf(wy, row.w, acc.w);
+        if (out2) {
+            acc2.x = fmaf(wy, row2.x, acc2.x); acc2.y = fmaf(wy, row2.y, acc2.y);
+            acc2.z = fmaf(wy, row2.z, acc2.z); acc2.w = fmaf(wy, row2.w, acc2.w);
+        }
     }
     const float s = 1.f / 16.f;
     float4 o = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
@@ -124,6 +145,7 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const float* __restrict__ i
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
     *reinterpret_cast<float4*>(out + off) = o;
+    if (out2) *reinterpret_cast<float4*>(out2 + off) = make_float4(acc2.x * s, acc2.y * s, acc2.z * s, acc2.w * s);
 }
 
 static int grid_for(int64_t total) {
@@ -133,27 +155,28 @@ static int grid_for(int64_t total) {
     return (int)blocks;
 }
 
-int launch_fir_down(const float* in, int B, int H, int W, int C, GnParams gn, int silu, float* out, hipStream_t s) {
+int launch_fir_down(const float* in, int B, int H, int W, int C, GnParams gn, int silu, float* out, hipStream_t s,
+                    float* out2) {
     if ((C & 3) || (H & 1) || (W & 1) || H / 2 > 65535 || B > 65535) {
         set_error("fir_down: unsupported shape B=%d H=%d W=%d C=%d", B, H, W, C);
         return ERR_SHAPE;
     }
     const unsigned per_row = (unsigned)(W / 2) * (C / 4);
     hipLaunchKernelGGL(fir_down_kernel, dim3((per_row + 255) / 256, H / 2, B), dim3(256), 0, s, in, H, W, C, gn, silu,
-                       out);
+                       out, out2);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
 
 int launch_fir_up(const float* in, int B, int H, int W, int C, GnParams gn, int silu, const float* add, float* out,
-                  hipStream_t s) {
+                  hipStream_t s, float* out2) {
     if ((C & 3) || H * 2 > 65535 || B > 65535) {
         set_error("fir_up: unsupported shape B=%d H=%d C=%d", B, H, C);
         return ERR_SHAPE;
     }
     const unsigned per_row = (unsigned)(W * 2) * (C / 4);
     hipLaunchKernelGGL(fir_up_kernel, dim3((per_row + 255) / 256, H * 2, B), dim3(256), 0, s, in, H, W, C, gn, silu, add,
-                       out);
+                       out, out2);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }

@@ -675,21 +675,27 @@ struct Builder {
     }
     size_t M_table_off = 0;     // arena offset of the Dense_0 bias table [B][dense_rows]
 
-    Tn fir(const Tn& a, bool up, const GnBuf* g, bool silu, const Tn* add, bool out_is_add = false) {
+    // raw_out (optional): receives the same resampling of the un-normalised input (one read of `a` for both)
+    Tn fir(const Tn& a, bool up, const GnBuf* g, bool silu, const Tn* add, bool out_is_add = false,
+           Tn* raw_out = nullptr) {
         flowse_model* M = m;
         const int H = a.H, Wd = a.W, C = a.C, Bn = B;
         Tn o = out_is_add ? *add : (up ? alloc(2 * H, 2 * Wd, C) : alloc(H / 2, Wd / 2, C));
-        const size_t a_off = a.off, o_off = o.off, add_off = add ? add->off : 0;
-        const bool hasg = g != nullptr, hasadd = add != nullptr;
+        if (raw_out) *raw_out = up ? alloc(2 * H, 2 * Wd, C) : alloc(H / 2, Wd / 2, C);
+        const size_t a_off = a.off, o_off = o.off, add_off = add ? add->off : 0, r_off = raw_out ? raw_out->off : 0;
+        const bool hasg = g != nullptr, hasadd = add != nullptr, hasraw = raw_out != nullptr;
         GnBuf gb = hasg ? *g : GnBuf();
+        const double outs = hasraw ? 2.0 : 1.0;
         op(std::string(up ? "fir_up@" : "fir_down@") + std::to_string(H) + "x" + std::to_string(Wd), [=](hipStream_t s) {
             GnParams p{nullptr, nullptr, nullptr};
             if (hasg) p = GnParams{M->A(gb.mean), M->A(gb.scale), M->W(gb.beta)};
             if (up)
                 return launch_fir_up(M->A(a_off), Bn, H, Wd, C, p, silu ? 1 : 0, hasadd ? M->A(add_off) : nullptr,
-                                     M->A(o_off), s);
-            return launch_fir_down(M->A(a_off), Bn, H, Wd, C, p, silu ? 1 : 0, M->A(o_off), s);
-        }, (up ? 8.0 * 4 : 32.0 / 4) * Bn * H * Wd * C, 4.0 * Bn * H * Wd * C * (up ? 5.0 : 1.25));
+                                     M->A(o_off), s, hasraw ? M->A(r_off) : nullptr);
+            return launch_fir_down(M->A(a_off), Bn, H, Wd, C, p, silu ? 1 : 0, M->A(o_off), s,
+                                   hasraw ? M->A(r_off) : nullptr);
+        }, (up ? 8.0 * 4 : 32.0 / 4) * Bn * H * Wd * C * outs,
+           4.0 * Bn * H * Wd * C * (up ? 1.0 + 4.0 * outs : 1.0 + 0.25 * outs));
         return o;
     }
 
@@ -712,8 +718,8 @@ struct Builder {
             if (mod.shortcut) xs = conv("conv2_1x1", x1, x2, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f);
         } else {
             GnBuf g0 = gn(x1, x2, mod.w_gn0_g, mod.w_gn0_b);
-            Tn hr = fir(x1, mod.up, &g0, true, nullptr);
-            Tn xr = fir(x1, mod.up, nullptr, false, nullptr);
+            Tn xr;
+            Tn hr = fir(x1, mod.up, &g0, true, nullptr, false, &xr);      // act(GN(x)) and x resampled in one pass
             gn_release(g0);
             h1 = conv("conv0_3x3", hr, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f, false, false,
                       nullptr, false, mod.wq_c0);
