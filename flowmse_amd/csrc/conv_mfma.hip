@@ -3,8 +3,10 @@
 //   out[m][n] = ( sum_{tap, ci} A[m][tap, ci] * Wp[n][tap][ci] + bias[n] + bias2[b(m)][n] + res[m][n] ) * scale
 //
 //   m = NHWC pixel (b, y, x), n = output channel, K = taps * Cin with the channel axis contiguous in both
-//   operands.  Default arithmetic: exact fp32 -- v_mfma_f32_32x32x2_f32 is bitwise an fmaf chain (no TF32 on
-//   gfx950).  Optional 16-bit operand modes (bf16x3 / bf16 / fp16) exist for the LDS-halo 3x3 kernel only.
+//   operands.  All arithmetic is fp32 (v_mfma_f32_32x32x2_f32; no TF32 on gfx950).  The direct kernels are bitwise
+//   an fmaf chain; the production 3x3 kernel uses the F(4,3) Winograd form (half the multiplies, fp32 rounding
+//   ~3x the direct sum's).  Optional 16-bit operand modes (bf16x3 / bf16 / fp16) exist for the direct LDS-halo
+//   3x3 kernel only.
 //
 // Replaces (reference): ddpm_conv3x3 / ddpm_conv1x1 (flowmse/backbones/ncsnpp_utils/layers.py:100-124) and
 // NIN (layers.py:546-555) as used by ResnetBlockBigGANpp (layerspp.py:245-274), AttnBlockpp (:75-91), the
@@ -13,19 +15,25 @@
 // GroupNorm + SiLU in front of every ResBlock conv (layerspp.py:246,265; fused into the halo staging) and the
 // statistics of the NEXT GroupNorm (fused into the epilogue).
 //
-// Kernels in this file (dispatch: launch_conv):
-//   conv3x3_halo_kernel        3x3, H % 8 == 0, W % 16 == 0, C % 32 == 0, >= 256 tiles: 8x16-pixel tile, the input
-//                              halo of a 32-channel chunk staged in LDS once and shared by all nine taps, optional
-//                              fused GroupNorm+SiLU on the way in.  The production kernel (~80 % of GPU time).
-//   conv3x3_halo_bf16_kernel   the same with bf16 / bf16x3 / fp16 operands (v_mfma_f32_32x32x16_*).
+// Kernels in this file (dispatch: launch_conv / launch_conv_cin4):
+//   conv3x3_f43_kernel         3x3, H % 8 == 0, W % 16 == 0, Cin % 32 == 0, Cout % 64 == 0, >= 256 blocks: F(4,3)
+//                              Winograd along the vertical axis; 8x16-pixel x 64-channel tile, 3 blocks per CU; the
+//                              input halo of a 32-channel chunk double-buffered in LDS (optional fused GroupNorm+SiLU
+//                              on the way in), transformed weights fetched from L2 in MFMA fragment order.  The
+//                              production kernel (~70 % of GPU time).  conv3x3_wino_kernel: the F(2,3) form.
+//   conv3x3_halo_kernel        the direct form of the same tiling (per-tap weight tile through LDS): narrow heads
+//                              (Cout = 4), FLOWSE_NO_WINOGRAD=1, and the base of
+//   conv3x3_halo_bf16_kernel   the bf16 / bf16x3 / fp16 operand modes (v_mfma_f32_32x32x16_*).
 //   conv_mfma_fast_kernel      flat pixel tiling, A gathered per tap through a window buffer descriptor: 1x1 convs
 //                              and 3x3 on small images; split-K (gridDim.y) + splitk_reduce[_stats] for tiny images.
 //   conv_mfma_kernel           generic fallback (any channel count multiple of 4, chunks straddling the concat).
-//   conv_cin4_kernel           direct VALU conv for the 4-channel input layer / Combine.
-// Common tiling: block = 4 waves; wave tile = TM x TN MFMA tiles of 32x32; block tile (WM*TM*32) x (WN*TN*32);
-// K walked in steps of (tap, 32-channel chunk); operands register-staged into double-buffered LDS with a row stride
-// of 36 floats (conflict-free ds_read_b128); each lane reads 4 consecutive k of its row once and feeds 4 successive
-// MFMAs (lanes 0-31 carry k = 8j+e, lanes 32-63 carry k = 8j+4+e, for A and B alike); epilogue through LDS.
+//   conv3x3_cin4_mfma_kernel   the 4 -> 128 input layer on the matrix cores (A operand = a neighbour pixel's float4).
+//   conv_cin4_kernel           direct VALU conv for 4 input channels (Combine 1x1, small / odd input layers).
+// Common to the LDS-staged kernels: block = 4 waves; LDS rows of 36 floats (conflict-free ds_read_b128); each lane
+// reads 4 consecutive k of its row once and feeds 4 successive MFMAs (lanes 0-31 carry k = 8j+e, lanes 32-63 carry
+// k = 8j+4+e, for A and B alike); epilogue through LDS (bias, temb bias, residual, scale, GroupNorm partials).
+// Environment switches (read once): FLOWSE_NO_WINOGRAD, FLOWSE_WINOGRAD=f23, FLOWSE_NO_HALO_CONV,
+// FLOWSE_FORCE_GENERIC_CONV, FLOWSE_NO_CIN4_MFMA -- test / A-B hooks, never needed for correctness.
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -1150,9 +1158,6 @@ int launch_wino_weights(const float* w_packed, int Cout, int Cin, float* out, hi
 // wave (wn, ch) owns output channels 32 wn .. +31 and the component half ch (0: m0..m2 from d0..d4, 1: m3..m5 from
 // d1..d5) -- 3 x 16 accumulators per lane.  The two halves of A^T m are added in the epilogue's LDS tile.  fp32
 // error of the 1-D F(4,3) form is ~3x the direct sum's (6e-7 vs 2e-7 rel-L2 on unit-variance data).
-#ifndef FLOWSE_HALO_AUX
-#define FLOWSE_HALO_AUX 0
-#endif
 constexpr int F43_HROW = 18 * LDS_ROW + 8;    // words per halo pixel row: 4 rows = 0 mod 64 banks (quad 1 vs quad 0)
 
 template <int GN, int CH>
@@ -1221,8 +1226,8 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
         const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * 4u;
         const unsigned cs = (unsigned)(second ? C2 : C1);
         const unsigned off = ((hin >> Q) & 1u) ? (hpix[Q] * cs + (unsigned)col4 * 4u) * 4u : OOB;
-        return second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, soff, FLOWSE_HALO_AUX)
-                      : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, soff, FLOWSE_HALO_AUX);
+        return second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, soff, 0)
+                      : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, soff, 0);
     };
     auto gparams = [&](int chunk) {
         if (GN) {
