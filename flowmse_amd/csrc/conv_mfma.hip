@@ -34,6 +34,7 @@
 // k = 8j+4+e, for A and B alike); epilogue through LDS (bias, temb bias, residual, scale, GroupNorm partials).
 // Environment switches (read once): FLOWSE_NO_WINOGRAD, FLOWSE_WINOGRAD=f23, FLOWSE_NO_HALO_CONV,
 // FLOWSE_FORCE_GENERIC_CONV, FLOWSE_NO_CIN4_MFMA -- test / A-B hooks, never needed for correctness.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -57,6 +58,22 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = b & 7, idx = b >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device setting: remember on which devices of this process the
+// kernel has been configured (one process normally drives one GPU, but nothing here relies on that).
+template <auto Kernel>
+static int allow_lds(size_t bytes) {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    FLOWSE_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)bytes));
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    return OK;
 }
 
 // ---- shared epilogue.  The accumulators go through LDS (C/D layout of the 32x32 MFMA: col = lane & 31,
@@ -718,14 +735,8 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     const size_t lds_stage = 2 * (BM + BN) * LDS_ROW * sizeof(float);
     const size_t lds_epi = ((size_t)BM * (BN + 4) + 64 * WM * WN * 8) * sizeof(float);
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    static bool attr_done = false;
-    if (!attr_done) {
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_fast_kernel<WM, WN, TM, TN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    if (const int rc = allow_lds<&conv_mfma_kernel<WM, WN, TM, TN>>(lds)) return rc;
+    if (const int rc = allow_lds<&conv_mfma_fast_kernel<WM, WN, TM, TN>>(lds)) return rc;
     // fast path: every K step is a full 32-channel chunk of one source; window / weight offsets fit 31 bits
     const bool fast = (a.C1 % KC) == 0 && (a.C2 % KC) == 0 &&
                       (int64_t)(BM + 2 * a.W + 2) * (a.C1 > a.C2 ? a.C1 : a.C2) * 4 < (1LL << 31) &&
@@ -886,16 +897,9 @@ static int launch_halo(const ConvArgs& a, hipStream_t s) {
     const size_t lds_stage = (180 + 2 * BN) * LDS_ROW * sizeof(float);
     const size_t lds_epi = ((size_t)BM * (BN + 4) + 64 * WM * WN * 8) * sizeof(float);
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    static bool attr_done = false;
-    if (!attr_done) {
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, TM, TN, 0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, TM, TN, 1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, TM, TN, 2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    if (const int rc = allow_lds<&conv3x3_halo_kernel<WM, WN, TM, TN, 0>>(lds)) return rc;
+    if (const int rc = allow_lds<&conv3x3_halo_kernel<WM, WN, TM, TN, 1>>(lds)) return rc;
+    if (const int rc = allow_lds<&conv3x3_halo_kernel<WM, WN, TM, TN, 2>>(lds)) return rc;
     if (a.gn.mean && a.gn_silu)
         hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, TM, TN, 2>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     else if (a.gn.mean)
@@ -1469,16 +1473,9 @@ static int launch_f43(const ConvArgs& a, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int grid = (int)(M / 128) * (a.Cout / 64);
     const size_t lds = 2 * 10 * F43_HROW * sizeof(float);              // two halo buffers; > the epilogue's 43 KB
-    static bool attr_done = false;
-    if (!attr_done) {
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f43_kernel<0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f43_kernel<1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f43_kernel<2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    if (const int rc = allow_lds<&conv3x3_f43_kernel<0>>(lds)) return rc;
+    if (const int rc = allow_lds<&conv3x3_f43_kernel<1>>(lds)) return rc;
+    if (const int rc = allow_lds<&conv3x3_f43_kernel<2>>(lds)) return rc;
     if (a.gn.mean && a.gn_silu)
         hipLaunchKernelGGL(conv3x3_f43_kernel<2>, dim3(grid), dim3(256), lds, s, a);
     else if (a.gn.mean)
@@ -1504,16 +1501,9 @@ static int launch_wino(const ConvArgs& a, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int grid = (int)(M / 128) * (a.Cout / 64);
     const size_t lds = 2 * 180 * LDS_ROW * sizeof(float);              // two halo buffers; > the <2,2,2,1> epilogue's 43 KB
-    static bool attr_done = false;
-    if (!attr_done) {
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    if (const int rc = allow_lds<&conv3x3_wino_kernel<0>>(lds)) return rc;
+    if (const int rc = allow_lds<&conv3x3_wino_kernel<1>>(lds)) return rc;
+    if (const int rc = allow_lds<&conv3x3_wino_kernel<2>>(lds)) return rc;
     if (a.gn.mean && a.gn_silu)
         hipLaunchKernelGGL(conv3x3_wino_kernel<2>, dim3(grid), dim3(256), lds, s, a);
     else if (a.gn.mean)
@@ -1835,14 +1825,8 @@ static int launch_halo_bf16(const ConvArgs& a, hipStream_t s) {
     const size_t lds_stage = (size_t)(180 + 2 * 128) * ROWB;
     const size_t lds_epi = ((size_t)128 * 132 + 256 * 8) * sizeof(float);
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    static bool attr_done = false;
-    if (!attr_done) {
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TERMS, false, F16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_bf16_kernel<TERMS, true, F16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    if (const int rc = allow_lds<&conv3x3_halo_bf16_kernel<TERMS, false, F16>>(lds)) return rc;
+    if (const int rc = allow_lds<&conv3x3_halo_bf16_kernel<TERMS, true, F16>>(lds)) return rc;
     if (a.gn.mean)
         hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TERMS, true, F16>), dim3(grid), dim3(256), lds, s, a);
     else
@@ -2022,12 +2006,7 @@ int launch_conv_cin4(const ConvArgs& a, hipStream_t s) {
     const int Q = a.Cout / 4;
     if (a.C1 == 4 && a.C2 == 0 && a.ksplit <= 1 && !a.gn.mean && conv_cin4_uses_mfma(a.B, a.H, a.W, a.Cout, a.taps)) {
         const size_t lds = ((size_t)128 * (128 + 4) + 256 * 8) * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {
-            FLOWSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_cin4_mfma_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_done = true;
-        }
+        if (const int rc = allow_lds<&conv3x3_cin4_mfma_kernel>(lds)) return rc;
         const int grid = (int)((int64_t)a.B * a.H * a.W / 128);
         hipLaunchKernelGGL(conv3x3_cin4_mfma_kernel, dim3(grid), dim3(256), lds, s, a);
         FLOWSE_LAUNCH_CHECK();
