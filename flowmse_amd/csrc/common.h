@@ -134,6 +134,8 @@ bool conv_supports_bf16(int B, int H, int W, int C1, int C2, int Cout, int taps)
 // true when launch_conv will run the LDS-halo 3x3 kernel for this shape (the only one that can normalise its
 // input on the fly)
 bool conv_supports_fused_gn(int B, int H, int W, int C1, int C2, int Cout, int taps);
+// true when the 4-output-channel 3x3 heads run the dedicated v_mfma_f32_4x4x1 kernel (fused GroupNorm input ok)
+bool conv_supports_head4(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // number of per-sample partial blocks a conv writes when stats fusion applies to this shape, else 0
 int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps);
 // with_reduce = false: a split-K launch only writes the partial slices (the caller runs launch_splitk_reduce)

@@ -860,6 +860,7 @@ static const bool g_no_wino_policy = getenv("FLOWSE_NO_WINOGRAD") != nullptr || 
                                      getenv("FLOWSE_FORCE_GENERIC_CONV") != nullptr;
 
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
+    if (conv_supports_head4(B, H, W, Cin, 0, Cout, taps)) return 1;     // 4-channel heads: dedicated kernel
     const int64_t M = (int64_t)B * H * W;
     const int bn = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;       // N tile launch_conv picks for this width
     const int64_t tiles = ((M + 127) / 128) * ((Cout + bn - 1) / bn);
@@ -882,6 +883,7 @@ int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
 static const bool g_no_halo = getenv("FLOWSE_NO_HALO_CONV") != nullptr;
 
 bool conv_supports_fused_gn(int B, int H, int W, int C1, int C2, int Cout, int taps) {
+    if (conv_supports_head4(B, H, W, C1, C2, Cout, taps)) return true;
     if (g_no_halo || g_force_generic) return false;
     if (taps != 9 || (H & 7) || (W & 15) || (C1 % KC) || (C2 % KC) || (Cout & 3)) return false;
     if (conv_ksplit(B, H, W, C1 + C2, Cout, taps) != 1) return false;
@@ -1143,6 +1145,139 @@ int launch_wino_weights(const float* w_packed, int Cout, int Cin, float* out, hi
     }
     const int64_t n = (int64_t)Cout * 3 * Cin;
     hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w_packed, Cout, Cin, out);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3x3 convolution to FOUR output channels: the progressive-output heads (ncsnpp.py:345-366,
+// pyramid = up(pyramid) + conv3x3(act(GroupNorm(h)))).  With N = 4 the 32-wide MFMA tiles would waste 7/8 of the
+// matrix work, so this kernel uses v_mfma_f32_4x4x1_16B_f32: sixteen independent 4 x 4 outer products per
+// instruction = 64 pixels x 4 channels x one k, no padding anywhere.  Lane l supplies pixel l of the wave's 4 x 16
+// pixel strip (A) and weight column l & 3 (B); accumulator register r of lane l holds pixel (l & ~3) + r, channel l & 3.
+// Block = 16 x 16 pixels, 4 waves; per 32-channel chunk the 18 x 18 halo (GroupNorm + SiLU fused as in the other
+// halo kernels) and the 4 x 9 x 32 weights sit in LDS; a lane's float4 fragment feeds four MFMAs.  HBM-read bound.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int GN>
+__global__ __launch_bounds__(256, 3) void conv3x3_head4_kernel(ConvArgs a) {
+    constexpr int HPIX = 18 * 18;                        // halo pixels
+    constexpr int H_LOADS = (HPIX * 8 + 255) / 256;      // 11 float4 per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                                    // [HPIX][LDS_ROW]
+    float* Ws = smem + HPIX * LDS_ROW;                   // [4][9][LDS_ROW]
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W;
+    const int Cin = a.C1;
+    const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 4);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bid / tiles_img, tt = bid - b * tiles_img;
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const int m_tl = (b * H + y0) * W + x0;
+
+    const int col4 = tid & 7, row0 = tid >> 3;
+    unsigned hvo[H_LOADS];
+    unsigned hin = 0;
+#pragma unroll
+    for (int q = 0; q < H_LOADS; ++q) {
+        const int hr = row0 + 32 * q;
+        const int hy = hr / 18, hx = hr - hy * 18;
+        const bool in = hr < HPIX && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+        hvo[q] = in ? (unsigned)((hy * W + hx) * Cin + col4 * 4) * 4u : OOB;
+        hin |= in ? (1u << q) : 0u;
+    }
+    const int64_t wbase = (int64_t)m_tl - W - 1;
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.in1 + wbase * Cin), 0, (17 * W + 18) * Cin * 4, 0x00020000);
+
+    u32x4 rh[H_LOADS];
+    float4 g_mu, g_sc, g_be, rw0, rw1;
+    auto gload = [&](int chunk) {
+        const unsigned soff = (unsigned)(chunk * KC) * 4u;
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) rh[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc1, hvo[q], soff, 0);
+        if (GN) {
+            const int cg = chunk * KC + col4 * 4;
+            g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
+            g_sc = *reinterpret_cast<const float4*>(a.gn.scale + (int64_t)b * Cin + cg);
+            g_be = *reinterpret_cast<const float4*>(a.gn.beta + cg);
+        }
+        // weights of this chunk: 4 x 9 rows of 8 float4 = 288 float4, thread t takes t and (t < 32) t + 256
+        rw0 = *reinterpret_cast<const float4*>(a.w + (int64_t)(tid >> 3) * Cin + chunk * KC + col4 * 4);
+        if (tid < 32) rw1 = *reinterpret_cast<const float4*>(a.w + (int64_t)(32 + (tid >> 3)) * Cin + chunk * KC + col4 * 4);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            const int hr = row0 + 32 * q;
+            if (GN) rh[q] = gn_quad<GN>(rh[q], g_mu, g_sc, g_be, (hin >> q) & 1u);
+            if (hr < HPIX) *reinterpret_cast<u32x4*>(Hs + hr * LDS_ROW + col4 * 4) = rh[q];
+        }
+        *reinterpret_cast<float4*>(Ws + (tid >> 3) * LDS_ROW + col4 * 4) = rw0;
+        if (tid < 32) *reinterpret_cast<float4*>(Ws + (32 + (tid >> 3)) * LDS_ROW + col4 * 4) = rw1;
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    // lane = pixel of the wave's 4 x 16 strip: row lane >> 4, column lane & 15 (halo coordinates +1)
+    const float* Ap = Hs + ((4 * wave + (lane >> 4)) * 18 + (lane & 15)) * LDS_ROW;
+    const float* Bp = Ws + (lane & 3) * 9 * LDS_ROW;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = Cin / KC;
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        gload(min(chunk + 1, nchunks - 1));              // next chunk into registers under this chunk's MFMAs
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* At = Ap + ((tap / 3) * 18 + (tap % 3)) * LDS_ROW;
+            const float* Bt = Bp + tap * LDS_ROW;
+#pragma unroll
+            for (int q = 0; q < KC / 4; ++q) {
+                const float4 av = *reinterpret_cast<const float4*>(At + q * 4);
+                const float4 bv = *reinterpret_cast<const float4*>(Bt + q * 4);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, bv.w, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                 // everyone has left this chunk's tiles
+        lstore();
+        __syncthreads();
+    }
+    // accumulator register r: pixel (lane & ~3) + r of the strip, channel lane & 3
+    const int j = lane & 3;
+    const float bj = a.bias ? a.bias[j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int p = (lane & ~3) + r;
+        const int64_t m = (int64_t)m_tl + (4 * wave + (p >> 4)) * W + (p & 15);
+        float v = acc[r] + bj;
+        if (a.res) v += a.res[m * 4 + j];
+        a.out[m * 4 + j] = v * a.scale;
+    }
+}
+
+bool conv_supports_head4(int B, int H, int W, int C1, int C2, int Cout, int taps) {
+    static const bool off = getenv("FLOWSE_NO_HEAD4") != nullptr;      // test / A-B hook
+    return !off && !g_force_generic && taps == 9 && Cout == 4 && C2 == 0 && (C1 % KC) == 0 && !(H & 15) && !(W & 15) &&
+           (int64_t)B * (H >> 4) * (W >> 4) >= 64 && (int64_t)(17 * W + 18) * C1 * 4 < (1LL << 31);
+}
+
+static int launch_head4(const ConvArgs& a, hipStream_t s) {
+    const int grid = a.B * (a.H >> 4) * (a.W >> 4);
+    const size_t lds = (size_t)(18 * 18 + 36) * LDS_ROW * sizeof(float);
+    if (a.gn.mean && a.gn_silu) {
+        hipLaunchKernelGGL(conv3x3_head4_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+    } else if (a.gn.mean) {
+        hipLaunchKernelGGL(conv3x3_head4_kernel<1>, dim3(grid), dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(conv3x3_head4_kernel<0>, dim3(grid), dim3(256), lds, s, a);
+    }
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
@@ -1863,6 +1998,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
         set_error("conv: too many pixels for 32-bit pixel indices");
         return ERR_SHAPE;
     }
+    if (a.ksplit <= 1 && !a.partial && !a.bias2 && !a.stats && conv_supports_head4(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))
+        return launch_head4(a, s);
     if (a.ksplit <= 1 && conv_supports_fused_gn(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
         if (a.wq && (a.Cout % 128) == 0) {
             if (a.terms == 3 && !a.wq_f16) return launch_halo_bf16<3>(a, s);

@@ -41,6 +41,8 @@ CONV_CASES = [
     (1, 2, 2, 512, 0, 256, 3, True, False, False, 1.0),        # deep K, tiny image
     (2, 128, 144, 4, 0, 128, 3, True, False, False, 1.0),      # input layer on the matrix cores (>= 256 blocks)
     (1, 256, 128, 4, 0, 128, 3, True, True, True, 0.5),
+    (4, 64, 64, 256, 0, 4, 3, True, False, True, 1.0),          # 4-channel head on the 4x4x1 MFMA kernel
+    (1, 144, 272, 64, 0, 4, 3, False, False, False, 0.5),       # same, 9 x 17 tiles, no bias / residual
 ]
 
 
