@@ -147,6 +147,7 @@ WINO_CASES = [
     (1, 128, 144, 32, 0, 192, False, False, 1.0, False),      # W = 9 tiles, three 64-wide N tiles
     (1, 256, 128, 64, 0, 64, False, True, 1.0, True),
     (8, 32, 32, 256, 256, 256, True, True, 0.70710678, True),   # one block per CU: preferred over split-K
+    (2, 72, 256, 64, 32, 128, True, True, 1.0, True),           # H = 9 tiles (odd), 64+32 concat, strip-major walk
 ]
 
 
