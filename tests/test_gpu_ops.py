@@ -190,6 +190,18 @@ def test_conv3x3_winograd(G, case, form):
     assert C.rel_l2(got0, ref0) < TOL
 
 
+def test_conv3x3_winograd_rejects_uncovered_shapes(G):
+    """The Winograd entry points refuse shapes their tiling does not cover (status SHAPE + message) instead of
+    silently running another kernel: small image, Cout not a multiple of 64, H not a multiple of 8."""
+    from flowmse_amd._lib import FlowseError
+    for (B, Cc, H, W, Cout) in ((1, 64, 32, 32, 64), (2, 64, 128, 128, 96), (2, 64, 100, 128, 64)):
+        x = rnd(61, (B, Cc, H, W))
+        w = rnd(62, (Cout, Cc, 3, 3), 0.05)
+        for form in ("f23", "f43"):
+            with pytest.raises(FlowseError, match="not covered"):
+                G.conv3x3_f23(x, w, form=form)
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 16, 8), (1, 128, 32, 32), (2, 16, 8, 8), (1, 512, 4, 4),
                                    (1, 256, 64, 64)])
 @pytest.mark.parametrize("silu", [True, False])
