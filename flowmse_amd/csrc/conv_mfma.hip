@@ -859,6 +859,24 @@ int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps) {
 static const bool g_no_wino_policy = getenv("FLOWSE_NO_WINOGRAD") != nullptr || getenv("FLOWSE_NO_HALO_CONV") != nullptr ||
                                      getenv("FLOWSE_FORCE_GENERIC_CONV") != nullptr;
 
+// Winograd plan for a 3x3 shape: 0 = not a Winograd shape (or too small even when sliced), 1 = the Winograd halo
+// kernel runs over the whole K, >= 2 = it runs split over that many slices of 32-channel chunks (deterministic
+// two-pass reduction as for the flat kernel).  The Winograd kernels tile N by 64, so 256 (pixel tile, channel
+// block) pairs -- one per CU -- already beat slicing K; below that, K is cut until ~512 blocks exist while every
+// slice keeps at least two chunks.  Only the F(4,3) kernel knows how to run a slice.
+static int wino_plan(int B, int H, int W, int Cin, int Cout, int taps) {
+    if (g_no_wino_policy || taps != 9 || (H & 7) || (W & 15) || (Cin % KC) || (Cout % 64)) return 0;
+    const int64_t blocks = ((int64_t)B * H * W / 128) * (Cout / 64);
+    if (blocks >= 256) return 1;
+    const int nchunks = Cin / KC;
+    if (!conv_wino_default_f43() || blocks < 16 || nchunks < 4) return 0;
+    int64_t ks = (512 + blocks - 1) / blocks;
+    if (ks > nchunks / 2) ks = nchunks / 2;
+    const int per = (int)((nchunks + ks - 1) / ks);
+    ks = (nchunks + per - 1) / per;                   // every slice non-empty
+    return ks >= 2 ? (int)ks : 0;
+}
+
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     if (conv_supports_head4(B, H, W, Cin, 0, Cout, taps)) return 1;     // 4-channel heads: dedicated kernel
     const int64_t M = (int64_t)B * H * W;
@@ -866,10 +884,8 @@ int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     const int64_t tiles = ((M + 127) / 128) * ((Cout + bn - 1) / bn);
     const int steps = ((Cin + KC - 1) / KC) * taps;
     if (tiles >= 256 || steps < 8) return 1;          // measured: 256 beats 128 and 64 at B = 1..8
-    // the Winograd halo kernels tile N by 64: one block per CU is already better than slicing K
-    if (taps == 9 && !(H & 7) && !(W & 15) && (Cin % KC) == 0 && (Cout % 64) == 0 && !g_no_wino_policy &&
-        (M / 128) * (Cout / 64) >= 256)
-        return 1;
+    const int wp = wino_plan(B, H, W, Cin, Cout, taps);
+    if (wp >= 1) return wp;
     int64_t want = (512 + tiles - 1) / tiles;
     int64_t maxs = steps / 4;
     int64_t ks = want < maxs ? want : maxs;
@@ -886,7 +902,8 @@ bool conv_supports_fused_gn(int B, int H, int W, int C1, int C2, int Cout, int t
     if (conv_supports_head4(B, H, W, C1, C2, Cout, taps)) return true;
     if (g_no_halo || g_force_generic) return false;
     if (taps != 9 || (H & 7) || (W & 15) || (C1 % KC) || (C2 % KC) || (Cout & 3)) return false;
-    if (conv_ksplit(B, H, W, C1 + C2, Cout, taps) != 1) return false;
+    const int ks = conv_ksplit(B, H, W, C1 + C2, Cout, taps);
+    if (ks != 1 && ks != wino_plan(B, H, W, C1 + C2, Cout, taps)) return false;    // only the Winograd kernel runs split
     const int64_t cmax = C1 > C2 ? C1 : C2;
     return (int64_t)(9 * W + 18) * cmax * 4 < (1LL << 31) && (int64_t)Cout * 9 * (C1 + C2) * 4 < (1LL << 31);
 }
@@ -1399,6 +1416,9 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     const int abase = (4 * (li >> 4) + CH) * F43_HROW + (li & 15) * LDS_ROW + kh * 4;
     // weight fragments: 24 KB per (32-channel slice, kx, chunk), [component 0..5][k-block][lane][4 floats]
     const int nchunks = Cin / KC;
+    // split-K: gridDim.y slices of consecutive chunks; each slice leaves a raw partial tile (the epilogue's split form)
+    const int per_slice = (nchunks + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int c_begin = (int)blockIdx.y * per_slice, c_end = min(nchunks, c_begin + per_slice);
     const unsigned wslice = (unsigned)((n0 >> 5) + wn) * 3u * (unsigned)nchunks;     // in 24 KB units
     const unsigned wvo = (unsigned)lane * 16u + (unsigned)CH * 3u * 4096u;
 
@@ -1411,8 +1431,8 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     {   // first chunk: all six quads at once (the accumulators are not live yet)
         u32x4 t[H_LOADS];
 #pragma unroll
-        for (int q = 0; q < H_LOADS; ++q) t[q] = hload(0, q);
-        gparams(0);
+        for (int q = 0; q < H_LOADS; ++q) t[q] = hload(c_begin, q);
+        gparams(c_begin);
 #pragma unroll
         for (int q = 0; q < H_LOADS; ++q) {
             if (GN) t[q] = gn_quad<GN>(t[q], g_mu, g_sc, g_be, (hin >> q) & 1u);
@@ -1485,13 +1505,13 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
 
     float4 dA[5], dB[5], bA[3], bB[3];
     {
-        const int chunk = 0;
+        const int chunk = c_begin;
         (void)chunk;
-        FLOWSE_WLOADB(0, 0, 0, bA)
+        FLOWSE_WLOADB(0, 0, c_begin, bA)
     }
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const float* Hcur = Hs + (chunk & 1) * HBUF;
-        const int cnext = min(chunk + 1, nchunks - 1), nbuf = (chunk + 1) & 1;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const float* Hcur = Hs + ((chunk - c_begin) & 1) * HBUF;
+        const int cnext = min(chunk + 1, c_end - 1), nbuf = (chunk - c_begin + 1) & 1;
         gloadH(cnext, 0);                                // next chunk's halo, first half
         FLOWSE_WLOADA(0, 0, dA)
         FLOWSE_WXA(dA) FLOWSE_WXB(dA)
@@ -1530,7 +1550,7 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     // This wave's half of A^T m, laid out like four 32-pixel tiles of the <2,2,2,1> epilogue: accumulator register
     // r holds quad row (r&3) + 8*(r>>2) + 4*kh, i.e. row quad r >> 3; output row 4*quad + o is tile row pair
     // 2*quad + (o >> 1), second row of the pair when o is odd -> tile-row index i = 2*(r>>3) + (o>>1), r' = (r&7) + 8*(o&1)
-    conv_epilogue_with<2, 2, 2, 1>(a, smem, m_tl, n0, M, HW, 0, W, [&](float* Cs, int CROW) {
+    conv_epilogue_with<2, 2, 2, 1>(a, smem, m_tl, n0, M, HW, (int)blockIdx.y, W, [&](float* Cs, int CROW) {
         float* Cw = Cs + wn * 32 + li;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -1607,16 +1627,17 @@ int launch_f43_weights(const float* w_packed, int Cout, int Cin, float* out, hip
 static int launch_f43(const ConvArgs& a, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int grid = (int)(M / 128) * (a.Cout / 64);
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;       // slices of 32-channel chunks (gridDim.y), see wino_plan
     const size_t lds = 2 * 10 * F43_HROW * sizeof(float);              // two halo buffers; > the epilogue's 43 KB
     if (const int rc = allow_lds<&conv3x3_f43_kernel<0>>(lds)) return rc;
     if (const int rc = allow_lds<&conv3x3_f43_kernel<1>>(lds)) return rc;
     if (const int rc = allow_lds<&conv3x3_f43_kernel<2>>(lds)) return rc;
     if (a.gn.mean && a.gn_silu)
-        hipLaunchKernelGGL(conv3x3_f43_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(conv3x3_f43_kernel<2>, dim3(grid, ks), dim3(256), lds, s, a);
     else if (a.gn.mean)
-        hipLaunchKernelGGL(conv3x3_f43_kernel<1>, dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(conv3x3_f43_kernel<1>, dim3(grid, ks), dim3(256), lds, s, a);
     else
-        hipLaunchKernelGGL(conv3x3_f43_kernel<0>, dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(conv3x3_f43_kernel<0>, dim3(grid, ks), dim3(256), lds, s, a);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
@@ -1629,7 +1650,7 @@ bool conv_wino_default_f43() {
 
 bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps) {
     return !g_no_wino && (Cout % 64) == 0 && conv_supports_fused_gn(B, H, W, C1, C2, Cout, taps) &&
-           (int64_t)Cout * 18 * (C1 + C2) * 4 < (1LL << 31);
+           wino_plan(B, H, W, C1 + C2, Cout, taps) >= 1 && (int64_t)Cout * 18 * (C1 + C2) * 4 < (1LL << 31);
 }
 
 static int launch_wino(const ConvArgs& a, hipStream_t s) {
@@ -1949,7 +1970,8 @@ void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst,
 }
 
 bool conv_supports_bf16(int B, int H, int W, int C1, int C2, int Cout, int taps) {
-    return (Cout % 128) == 0 && conv_supports_fused_gn(B, H, W, C1, C2, Cout, taps);
+    return (Cout % 128) == 0 && conv_supports_fused_gn(B, H, W, C1, C2, Cout, taps) &&
+           conv_ksplit(B, H, W, C1 + C2, Cout, taps) == 1;              // the 16-bit kernel has no split form
 }
 
 template <int TERMS, bool F16 = false>
@@ -2018,12 +2040,18 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
         if (tiles128 < 512) return launch_halo<2, 2, 2, 1>(a, s);
         return launch_halo<2, 2, 2, 2>(a, s);
     }
-    if (a.gn.mean) {
-        set_error("conv: fused GroupNorm input requested for a shape the halo kernel does not cover");
-        return ERR_ARG;
-    }
     if (a.ksplit > 1 && !a.partial) {
         set_error("conv: split-K needs a partial buffer");
+        return ERR_ARG;
+    }
+    if (a.ksplit > 1 && a.wino && a.wino_f43 && conv_supports_wino(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps) &&
+        a.ksplit == wino_plan(a.B, a.H, a.W, a.C1 + a.C2, a.Cout, a.taps)) {
+        const int rc = launch_f43(a, s);              // gridDim.y = ksplit slices of chunks, raw partial tiles
+        if (rc != OK || !with_reduce) return rc;
+        return launch_splitk_reduce(a, s);
+    }
+    if (a.gn.mean) {
+        set_error("conv: fused GroupNorm input requested for a shape the halo kernel does not cover");
         return ERR_ARG;
     }
     const int rc = a.Cout <= 32 ? launch_cfg<4, 1, 1, 1>(a, s)

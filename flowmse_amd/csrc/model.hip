@@ -1403,6 +1403,11 @@ static int op_conv3x3_winograd(int f43, const float* in1, int C1, const float* i
     c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = 9; c.scale = scale;
     c.wino = wf;
     c.wino_f43 = f43;
+    const int ks = conv_ksplit(B, H, W, C, Cout, 9);
+    if (f43 && ks > 1) {                           // same split plan as the model handle uses for this shape
+        c.ksplit = ks;
+        c.partial = wf + conv_wino_numel(Cout, C);
+    }
     if (gamma) {
         const int G = std::min(C / 4, 32);
         const int nblk = gn_partial_blocks(HW, C);
@@ -1420,7 +1425,9 @@ static int op_conv3x3_winograd(int f43, const float* in1, int C1, const float* i
 }
 
 int64_t flowse_op_conv3x3_f23_scratch_floats(int B, int H, int W, int C, int Cout) {
-    return flowse_op_group_norm_scratch_floats(B, H * W, C) + conv_wino_numel(Cout, C);
+    const int ks = conv_ksplit(B, H, W, C, Cout, 9);                   // > 1: F(4,3) runs split over K (small images)
+    return flowse_op_group_norm_scratch_floats(B, H * W, C) + conv_wino_numel(Cout, C) +
+           (ks > 1 ? (int64_t)ks * B * H * W * Cout : 0);
 }
 
 int flowse_op_conv3x3_f23(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
