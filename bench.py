@@ -10,6 +10,12 @@ architecture.  Inputs are resident in HBM before the timed region.  With N > 1 G
 batch (per-utterance data parallel, weak scaling); the only collective is the final RCCL gather of the
 enhanced spectrograms.  Rank 0 prints ONE JSON line.
 
+Launch forms (both give one process per GPU over RCCL):
+    python bench.py --gpus N ...                      bench.py spawns N ranks itself (torch.distributed.run)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...    (the driver's form)
+A run can never silently measure fewer GPUs than asked: N ranks need N visible devices, unless the test hook
+FLOWSE_BENCH_SHARE_GPU=1 maps every rank to device 0 (then FLOWSE_BENCH_BACKEND=gloo, RCCL cannot share a device).
+
 Metric: enhanced spectrogram-frames/sec at N=5 solver steps (frame = one STFT column of 256 bins).
 """
 import argparse
@@ -27,6 +33,8 @@ import torch.distributed as dist
 
 FLOP_PER_FRAME_NFE = 2.080e9          # 532.57 GFLOP / 256 frames (T=256)
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 (= fp32 vector peak)
+PEAK_16BIT_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (v_mfma_f32_32x32x16_*)
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 FULL_CFG = dict(nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,), image_size=256)
 
 
@@ -89,6 +97,21 @@ def cpu_baseline(sd, nsolver, frames, reps, budget_s=60.0):
                       f"(the path is linear in batch and steps)"}
 
 
+def spawn_ranks(n):
+    """Re-execute this script as n ranks on this node (one per GPU) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,16 +131,23 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="per-op timing table to stderr (extra untimed pass)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:         # plain `python bench.py --gpus N`: spawn the ranks
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: refusing to measure a different GPU count"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    if os.environ.get("FLOWSE_BENCH_SHARE_GPU"):                 # test hook: every rank on device 0
+    share = bool(os.environ.get("FLOWSE_BENCH_SHARE_GPU"))
+    if share:                                                    # test hook: every rank on device 0
         local_rank = 0
+    else:
+        assert torch.cuda.device_count() >= world, (
+            f"--gpus {world} needs {world} visible devices, found {torch.cuda.device_count()} "
+            "(set FLOWSE_BENCH_SHARE_GPU=1 FLOWSE_BENCH_BACKEND=gloo to run the ranks on one device for testing)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = os.environ.get("FLOWSE_BENCH_BACKEND", "nccl")     # "gloo": CI on a box where ranks share one GPU
@@ -180,17 +210,21 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = model.dnn.profile_end()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    per_rank_ms = [1e3 * elapsed / args.steps]
+    if world > 1:                                  # MAX over ranks is the job's time; keep every rank's own clock too
+        tt = torch.zeros(world, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        tt[rank] = elapsed
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        per_rank_ms = [1e3 * float(v) / args.steps for v in tt.tolist()]
+        elapsed = float(tt.max().item())
     assert torch.isfinite(torch.view_as_real(x)).all(), "non-finite output"
 
     frames_total = world * args.steps * B * T
     value = frames_total / elapsed
-    nfe_per_step = NS * {"euler": 1, "heun": 2, "rk4": 4}[args.solver]
+    # higher-order solvers take the reference's Euler update on the last step (it lands on t = 0): 1 NFE there
+    nfe_per_step = (NS - 1) * {"euler": 1, "heun": 2, "rk4": 4}[args.solver] + 1
     out = {
-        "metric": "enhanced spectrogram-frames/sec at N=5 solver steps",
+        "metric": f"enhanced spectrogram-frames/sec at N={NS} solver steps",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 (3x3 convs as split-bf16 x3 MFMA, fp32 accumulate)",
@@ -202,7 +236,10 @@ def main():
                                f"weights), precision mode {args.precision}",
                    "global_batch": world * B, "frames": T, "solver_steps": NS,
                    "parallelism": f"dp{world} (per-utterance, final RCCL gather only)",
+                   "collective_backend": (backend if world > 1 else None),
+                   "ranks_share_one_device": share if world > 1 else False,
                    "workspace_GB": round(ws_bytes / 2 ** 30, 2)},
+        "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
         "achieved_TFLOPs_whole_path": value * nfe_per_step * FLOP_PER_FRAME_NFE / world / 1e12,
     }
     if rank == 0:
@@ -210,13 +247,15 @@ def main():
         if dom and dom["ms"] > 0:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-            if os.path.exists(tpath) and (B, T, NS) == (8, 256, 5):      # PMC passes were taken on this workload
-                tj = json.load(open(tpath))
+            import glob
+            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))
+            if tfiles and (B, T, NS, args.precision) == (8, 256, 5, "fp32"):   # PMC passes were taken on this workload
+                tj = json.load(open(tfiles[-1]))
                 k = tj.get("dominant_kernel")
                 if k:
                     traffic = tj["kernels"][k]["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes)"
+                    traffic_src = (f"profiles/{os.path.basename(tfiles[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                   "own passes, 2*FETCH_SIZE + WRITE_SIZE)")
             form = None
             if args.precision == "fp32" and not os.environ.get("FLOWSE_NO_WINOGRAD"):
                 form = "F(2,3)" if os.environ.get("FLOWSE_WINOGRAD") == "f23" else "F(4,3)"
@@ -226,15 +265,19 @@ def main():
                      "flowse::conv3x3_halo_kernel<2,2,2,2,2> (fp32 implicit-GEMM 3x3 conv, 128x128 tile, LDS halo, "
                      "fused GroupNorm+SiLU input)" if args.precision == "fp32" else
                      "flowse::conv3x3_halo_bf16_kernel (16-bit operand variant of the halo kernel)")
-            issue = {"F(4,3)": 0.5, "F(2,3)": 2.0 / 3.0, None: 1.0}[form]
+            issue = {"F(4,3)": 0.5, "F(2,3)": 2.0 / 3.0, None: 3.0 if args.precision == "bf16x3" else 1.0}[form]
             issued = ach * issue
+            peak = PEAK_FP32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_16BIT_MATRIX_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": kname,
-                               "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MATRIX_TFLOPS,
-                               "achieved_definition": "algorithmic direct-convolution FLOPs (SURVEY 8d) / launch time"
-                                                      + (f"; {form} Winograd issues {issue:.3g} of them on the matrix "
-                                                         "cores (mfma_issued)" if form else ""),
-                               "mfma_issued": issued, "mfma_issued_frac": issued / PEAK_FP32_MATRIX_TFLOPS,
+                               "achieved": issued, "peak": peak, "unit": "TFLOP/s",
+                               "frac": issued / peak,
+                               "achieved_definition": "FLOPs the matrix cores execute per launch / launch time"
+                                                      + (f": {form} Winograd issues {issue:.3g} of the algorithmic "
+                                                         "direct-convolution FLOPs (SURVEY 8d), which are reported as "
+                                                         "achieved_algorithmic" if form else
+                                                         " (= the algorithmic direct-convolution FLOPs of SURVEY 8d)"),
+                               "achieved_algorithmic": ach,
+                               "whole_path_algorithmic_TFLOPs": value * nfe_per_step * FLOP_PER_FRAME_NFE / world / 1e12,
                                "traffic": traffic, "traffic_source": traffic_src,
                                "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                                "flops_per_launch_avg": dom["flops"] / dom["launches"],

@@ -5,6 +5,8 @@ Reference: flowmse/model.py:19-206.  What evaluate.py uses (evaluate.py:64-132):
 ``_forward_transform``, ``to_audio`` and the model itself as ``VF_fn(x, t, y)`` (= ``-dnn(cat[x,y], t)``,
 model.py:164-170).  Training (loss, optimizer, Lightning hooks, dataloaders) is out of scope.
 """
+import pickle
+import types
 import warnings
 
 import torch
@@ -13,6 +15,78 @@ import torch.nn as nn
 from flowmse_amd.backbones import BackboneRegistry
 from flowmse_amd.data_module import SpecTransform
 from flowmse_amd.odes import ODERegistry
+
+
+# ---------------------------------------------------------------------------------------------- checkpoint reader
+# A reference checkpoint pickles class references from packages that are absent on an inference box:
+# hyper_parameters['data_module_cls'] = flowmse.data_module.SpecsDataModule (train.py:58,66 -> save_hyperparameters,
+# model.py:66), and Lightning may wrap hyper_parameters in its AttributeDict.  None of them carries information the
+# sampler needs, so unknown globals from those packages unpickle to inert placeholders instead of failing.
+_FOREIGN_PREFIXES = ("flowmse", "sgmse", "pytorch_lightning", "lightning", "lightning_fabric", "torch_ema",
+                     "torchmetrics", "wandb", "omegaconf")
+
+
+class _ForeignDict(dict):
+    """Placeholder for dict-like foreign containers (e.g. pytorch_lightning AttributeDict)."""
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+
+
+def _foreign_placeholder(module, name):
+    if name in ("AttributeDict", "DictConfig"):
+        return _ForeignDict
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+
+    return type(name, (), {"__module__": module, "__init__": __init__, "__setstate__": __setstate__,
+                           "_flowse_foreign": True, "__reduce_ex__": object.__reduce_ex__})
+
+
+class _CkptUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except (ImportError, AttributeError):
+            if module.split(".")[0] in _FOREIGN_PREFIXES:
+                return _foreign_placeholder(module, name)
+            raise
+
+
+_ckpt_pickle = types.SimpleNamespace(__name__="flowmse_amd_ckpt_pickle", Unpickler=_CkptUnpickler, load=pickle.load,
+                                     loads=pickle.loads, dump=pickle.dump, dumps=pickle.dumps,
+                                     UnpicklingError=pickle.UnpicklingError, PickleError=pickle.PickleError)
+
+
+def read_checkpoint(path, map_location="cpu"):
+    """torch.load for a reference (Lightning) checkpoint that works without flowmse / pytorch_lightning /
+    torch_ema installed: class references into those packages become placeholders."""
+    return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_ckpt_pickle)
+
+
+def _is_foreign(v):
+    return getattr(v, "_flowse_foreign", False) or getattr(type(v), "_flowse_foreign", False)
+
+
+# constructor keywords the facade understands (VFModel + NCSNpp + FLOWMATCHING + SpecTransform); every other
+# hyper-parameter of a training run (dataset paths, loader settings, ...) is ignored with no effect
+_KNOWN_HPARAMS = {
+    "backbone", "ode", "lr", "ema_decay", "t_eps", "T_rev", "loss_abs_exponent", "num_eval_files", "loss_type",
+    # NCSNpp (ncsnpp.py:45-67)
+    "scale_by_sigma", "nonlinearity", "nf", "ch_mult", "num_res_blocks", "attn_resolutions", "resamp_with_conv",
+    "conditional", "fir", "fir_kernel", "skip_rescale", "resblock_type", "progressive", "progressive_input",
+    "progressive_combine", "init_scale", "fourier_scale", "image_size", "embedding_type", "dropout",
+    # FLOWMATCHING (odes.py:66-68)
+    "sigma_min", "sigma_max",
+    # spectrogram transform half of SpecsDataModule (data_module.py:96-105)
+    "n_fft", "hop_length", "window", "spec_factor", "spec_abs_exponent", "transform_type",
+}
 
 
 class VFModel(nn.Module):
@@ -58,14 +132,17 @@ class VFModel(nn.Module):
     def load_from_checkpoint(cls, checkpoint_file, map_location="cpu", **overrides):
         """Parse a Lightning checkpoint of the reference without Lightning / torch_ema
         (layout: SURVEY.md section 5: hyper_parameters, state_dict['dnn.*'], ema['shadow_params'])."""
-        ckpt = torch.load(checkpoint_file, map_location=map_location, weights_only=False)
+        ckpt = read_checkpoint(checkpoint_file, map_location)
         hp = dict(ckpt.get("hyper_parameters", {}))
-        hp.pop("data_module_cls", None)
-        for k in ("base_dir", "batch_size", "num_workers", "kwargs"):
-            overrides.pop(k, None)
-        hp.update(overrides)
+        hp.update(overrides)                      # evaluate.py:64-67 passes base_dir / batch_size / num_workers / kwargs
+        hp.pop("data_module_cls", None)           # class reference (placeholder here); SpecTransform stands in
+        dropped = sorted(k for k in hp if k not in _KNOWN_HPARAMS)
+        hp = {k: v for k, v in hp.items() if k in _KNOWN_HPARAMS and not _is_foreign(v)}
         model = cls(**hp)
+        model.ignored_hparams = dropped
         sd = {k[len("dnn."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("dnn.")}
+        if not sd:
+            raise KeyError("checkpoint state_dict has no 'dnn.*' entries (not a flowmse VFModel checkpoint?)")
         model.dnn.load_state_dict(sd)
         ema = ckpt.get("ema")
         if ema is not None and "shadow_params" in ema:

@@ -4,6 +4,13 @@
 solvers registered through the same plugin point (the reference has none: its only Runge-Kutta is the adaptive
 scipy RK45 black box of flowmse/sampling/__init__.py:64-114); they integrate the same dx/dt = VF(x,t,y)
 backwards in time with the reference's step rule.
+
+The network is only defined for t in [t_eps, T]: it divides by t (ncsnpp.py:398) and embeds log t.  The reference's
+step rule makes the LAST step as long as the last grid time (sampling/__init__.py:53), i.e. it lands on t = 0, so a
+higher-order stage evaluated at t + dt (or t + dt/2) of that step would query the field at / next to its
+singularity.  The higher-order solvers therefore take a plain Euler update whenever a step reaches t = 0 (exactly
+what the reference's own solver does there) and never evaluate the field at a time below the step's start ... end
+range of an interior step, all of which are >= t_eps.
 """
 import abc
 
@@ -26,6 +33,13 @@ def axpy(x, k, dt):
                                             _lib.current_stream()))
         return out
     return x + k * dt
+
+
+def _lands_on_zero(t, stepsize):
+    """True when the step [t, t - stepsize] ends at (or numerically below) t = 0: the final step of the reference's
+    grid, whose length equals the last grid time."""
+    t0 = float(t.flatten()[0]) if torch.is_tensor(t) else float(t)
+    return t0 - float(stepsize) <= 1e-6 * max(1.0, abs(t0))
 
 
 class ODEsolver(abc.ABC):
@@ -57,8 +71,9 @@ class HeunODEsolver(ODEsolver):
     def update_fn(self, x, t, y, stepsize, *args):
         dt = -stepsize
         k1 = self.VF_fn(x, t, y)
-        t2 = torch.clamp(t + dt, min=1e-4)          # the network divides by t
-        k2 = self.VF_fn(axpy(x, k1, dt), t2, y)
+        if _lands_on_zero(t, stepsize):              # final step: Euler (the field is singular at its end point)
+            return axpy(x, k1, dt)
+        k2 = self.VF_fn(axpy(x, k1, dt), t + dt, y)
         return axpy(axpy(x, k1, 0.5 * dt), k2, 0.5 * dt)
 
 
@@ -69,9 +84,10 @@ class RK4ODEsolver(ODEsolver):
 
     def update_fn(self, x, t, y, stepsize, *args):
         dt = -stepsize
-        th = torch.clamp(t + 0.5 * dt, min=1e-4)
-        te = torch.clamp(t + dt, min=1e-4)
         k1 = self.VF_fn(x, t, y)
+        if _lands_on_zero(t, stepsize):              # final step: Euler (the field is singular at its end point)
+            return axpy(x, k1, dt)
+        th, te = t + 0.5 * dt, t + dt
         k2 = self.VF_fn(axpy(x, k1, 0.5 * dt), th, y)
         k3 = self.VF_fn(axpy(x, k2, 0.5 * dt), th, y)
         k4 = self.VF_fn(axpy(x, k3, dt), te, y)

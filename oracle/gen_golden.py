@@ -17,7 +17,8 @@ Safety stubs:
     and are replaced by inert fakes (none of them is on the hot path);
   * sys.dont_write_bytecode so nothing is written under /root/reference.
 
-Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz)
+Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz and the checkpoint fixture)
+        python oracle/gen_golden.py ckpt       (only tests/golden/tiny_ckpt.ckpt + ckpt_forward.npz)
 """
 import os
 import sys
@@ -164,9 +165,59 @@ def param_table(model):
     return names, shapes, order
 
 
+CKPT_CFG = dict(nf=16, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(16,), image_size=32)
+
+
+@torch.no_grad()
+def make_checkpoint_fixture():
+    """A checkpoint in the layout the reference's training writes (train.py:58-66 -> model.py:58,66,81-90):
+    Lightning top-level keys, ``state_dict`` of the whole VFModel (``dnn.*``), ``hyper_parameters`` = every
+    constructor argument INCLUDING the pickled class reference ``data_module_cls`` =
+    flowmse.data_module.SpecsDataModule, and ``ema`` = torch_ema 0.3 ``ExponentialMovingAverage.state_dict()``
+    (decay, num_updates, shadow_params over the requires_grad parameters in ``parameters()`` order,
+    collected_params).  Weights are synthetic; the EMA shadow differs from the raw weights so that
+    ``eval(no_ema=False)`` / ``eval(no_ema=True)`` are distinguishable.  Also stores the reference's outputs for
+    both weight sets (tests/golden/ckpt_forward.npz)."""
+    from flowmse.data_module import SpecsDataModule
+    from flowmse.model import VFModel
+    hp = dict(backbone="ncsnpp", ode="flowmatching", lr=1e-4, ema_decay=0.999, t_eps=0.03, T_rev=1.0,
+              loss_abs_exponent=0.5, num_eval_files=10, loss_type="mse", data_module_cls=SpecsDataModule,
+              sigma_min=0.0, sigma_max=0.487,
+              base_dir="/data/WSJ0-CHiME3", format="default", batch_size=8, n_fft=510, hop_length=128,
+              num_frames=256, window="hann", num_workers=4, dummy=False, spec_factor=0.15, spec_abs_exponent=0.5,
+              normalize="noisy", transform_type="exponent", **CKPT_CFG)
+    model = VFModel(**hp)
+    load_synth(model.dnn, "", seed=0)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert all(k.startswith("dnn.") for k in sd)
+    trainable = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    shadow = [torch.from_numpy(synth.synth_param(n[len("dnn."):], tuple(p.shape), 1)) for n, p in trainable]
+    ckpt = {"epoch": 7, "global_step": 4321, "pytorch-lightning_version": "1.6.5",
+            "state_dict": sd, "loops": {}, "callbacks": {}, "optimizer_states": [], "lr_schedulers": [],
+            "hparams_name": "kwargs", "hyper_parameters": hp,
+            "ema": {"decay": 0.999, "num_updates": 4321, "shadow_params": shadow, "collected_params": None}}
+    path = os.path.join(OUT, "tiny_ckpt.ckpt")
+    torch.save(ckpt, path)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.1f} KB)")
+
+    B, Fq, T = 2, 32, 64
+    xt = c64(synth.complex_normal(21, 1, (B, 1, Fq, T), 0.5))
+    y = c64(synth.synth_spectrogram(7, B, Fq, T))
+    t = torch.tensor([0.2725, 0.8])
+    model.eval()                                     # EMA stub is inert: weights below are set by hand
+    out_raw = model(xt, t, y)
+    for (n, p), s in zip(trainable, shadow):         # what ema.copy_to(parameters()) does (model.py:97-99)
+        p.copy_(s)
+    out_ema = model(xt, t, y)
+    save("ckpt_forward", t=t, out_raw=out_raw, out_ema=out_ema)
+
+
 @torch.no_grad()
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "ckpt" in sys.argv[1:]:
+        make_checkpoint_fixture()
+        return
     act = nn.SiLU()
 
     # ---- parameter tables (key contract) --------------------------------------
@@ -274,6 +325,8 @@ def main():
     outf = full(torch.cat([xt, yf], dim=1), tf)
     save("full_forward_T64", t=tf, out=outf)
     print("full forward |out| rms:", float(outf.abs().pow(2).mean().sqrt()))
+
+    make_checkpoint_fixture()
 
 
 if __name__ == "__main__":

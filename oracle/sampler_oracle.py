@@ -39,3 +39,30 @@ def euler_sample(VF_fn, Y, z, T_rev=1.0, t_eps=0.03, N=30, sigma_min=0.0, sigma_
 
 def euler_sample_net(weights, cfg, Y, z, **kw):
     return euler_sample(lambda x, t, y: vf_forward(weights, cfg, x, t, y), Y, z, **kw)
+
+
+def rk_sample(VF_fn, Y, z, tableau="rk4", T_rev=1.0, t_eps=0.03, N=30, sigma_min=0.0, sigma_max=0.487):
+    """Fixed-step Heun / classical RK4 over the reference's time grid and step rule.  The reference has no
+    fixed-step Runge-Kutta (its only RK is scipy's adaptive RK45, sampling/__init__.py:64-114), so this is pinned
+    by COMPOSITION: the reference-pinned vector field inside the textbook tableau.  The last step of the grid
+    lands on t = 0 where the field (h / t, log t) is singular; like the reference's own solver it is an Euler step."""
+    with torch.no_grad():
+        xt = prior_sampling(Y, z, sigma_min, sigma_max)
+        ts, steps = time_grid(T_rev, t_eps, N)
+        for i in range(N):
+            t = torch.ones(Y.shape[0]) * ts[i]
+            dt = -steps[i]
+            k1 = VF_fn(xt, t, Y)
+            if i == N - 1:
+                xt = xt + k1 * dt
+            elif tableau == "heun":
+                k2 = VF_fn(xt + k1 * dt, t + dt, Y)
+                xt = xt + (k1 + k2) * (0.5 * dt)
+            elif tableau == "rk4":
+                k2 = VF_fn(xt + k1 * (0.5 * dt), t + 0.5 * dt, Y)
+                k3 = VF_fn(xt + k2 * (0.5 * dt), t + 0.5 * dt, Y)
+                k4 = VF_fn(xt + k3 * dt, t + dt, Y)
+                xt = xt + (k1 + 2 * k2 + 2 * k3 + k4) * (dt / 6.0)
+            else:
+                raise ValueError(tableau)
+        return xt

@@ -77,25 +77,22 @@ def test_generic_solver_loop_matches_fused(tiny):
     assert C.rel_l2(generic.cpu(), fused.cpu()) < 1e-6
 
 
-def test_heun_against_oracle_composition(tiny):
-    """Fixed-step RK has no reference counterpart: pinned by composing the oracle VF in the same tableau."""
-    from flowmse_amd.sampling import get_white_box_solver, time_grid
+@pytest.mark.parametrize("solver,N", [("heun", 3), ("rk4", 2)])
+def test_fixed_step_rk_against_oracle_composition(tiny, solver, N):
+    """Fixed-step RK (BASELINE config 5's solver) has no reference counterpart: pinned by composing the oracle VF in
+    the same tableau (oracle/sampler_oracle.py:rk_sample), final step = Euler (never evaluates below t_eps)."""
+    from flowmse_amd.sampling import get_white_box_solver
     from oracle import ncsnpp_oracle as O
     from oracle import sampler_oracle as S
     t = C.param_tables()["tiny"]
     w = C.synth_weights(t["names"], t["shapes"])
     cfg = O.make_cfg(**C.TINY)
     _, y, z = C.tiny_inputs()
-    x = S.prior_sampling(y, z)
-    ts, steps = time_grid(1.0, 0.03, 3)
-    for i in range(3):
-        dt = -steps[i]
-        tv = torch.ones(2) * ts[i]
-        k1 = O.vf_forward(w, cfg, x, tv, y)
-        k2 = O.vf_forward(w, cfg, x + k1 * dt, torch.clamp(tv + dt, min=1e-4), y)
-        x = x + (k1 + k2) * (0.5 * dt)
-    got = get_white_box_solver("heun", tiny.ode, tiny, Y=y.cuda(), N=3, z=z.cuda())()[0]
-    assert C.rel_l2(got.cpu(), x) < 5 * TIGHT
+    want = S.rk_sample(lambda x, tt, yy: O.vf_forward(w, cfg, x, tt, yy), y, z, tableau=solver, N=N)
+    got, n = get_white_box_solver(solver, tiny.ode, tiny, Y=y.cuda(), N=N, z=z.cuda())()
+    err = C.rel_l2(got.cpu(), want)
+    print(solver, "N", N, "rel-L2 vs oracle composition", err)
+    assert n == N and err < 5 * TIGHT
 
 
 def test_wide_forward_golden():

@@ -120,6 +120,35 @@ def test_generic_white_box_solver_on_cpu_callable():
     assert torch.allclose(x, torch.zeros_like(x), atol=1e-6)
 
 
+@pytest.mark.parametrize("solver", ["heun", "rk4"])
+def test_higher_order_solvers_never_leave_the_field_domain(solver):
+    """The field is only defined on [t_eps, T] (h / t and log t, ncsnpp.py:259,398): a solver must never query
+    below t_eps.  dx/dt = x / t is singular at t = 0 (exact solution x(t) = x(1) t); the last step, which lands on
+    t = 0, must be the reference's Euler step."""
+    from flowmse_amd.odes import FLOWMATCHING
+    from flowmse_amd.sampling import get_white_box_solver, time_grid
+    from oracle import sampler_oracle as S
+    ode = FLOWMATCHING()
+    Y = torch.full((2, 1, 2, 2), 1.0 + 0.5j, dtype=torch.complex64)
+    z = torch.zeros_like(Y)
+    seen = []
+
+    def vf(x, t, y):
+        seen.append(float(t.min()))
+        return x / t.reshape(-1, 1, 1, 1)
+
+    N, t_eps = 4, 0.03
+    x, n = get_white_box_solver(solver, ode, vf, Y=Y, N=N, z=z, t_eps=t_eps)()
+    assert n == N and min(seen) >= t_eps - 1e-7, seen
+    assert torch.isfinite(torch.view_as_real(x)).all()
+    want = S.rk_sample(lambda xx, tt, yy: xx / tt.reshape(-1, 1, 1, 1), Y, z, tableau=solver, N=N, t_eps=t_eps)
+    assert torch.allclose(x, want, rtol=1e-5, atol=1e-7)
+    # interior steps integrate x / t almost exactly, the Euler step from t_eps lands on exactly 0 for this field
+    assert float(x.abs().max()) < 1e-3
+    ts, steps = time_grid(1.0, t_eps, N)
+    assert float(steps[-1]) == float(ts[-1])
+
+
 def test_ema_swap_semantics():
     """eval(no_ema=False) swaps the EMA shadow weights in, train() restores (model.py:92-103)."""
     from flowmse_amd.model import VFModel
