@@ -187,9 +187,26 @@ int launch_upfirdn2d_nchw(const float* in, const float* kernel, int planes, int 
 int launch_attention(const float* qkv, int B, int L, int C, float* out, hipStream_t s);
 
 // ------------------------------------------------------------------ small ops
-int launch_pack_input(const float* x_c64, const float* y_c64, int B, int F, int T, float* out4, hipStream_t s);
+// Per-call arguments of the network's boundary kernels (feature pack, time embedding, head).  They live in DEVICE
+// memory (one block per model handle, rewritten by a one-thread kernel whose argument is the new value) so that the
+// launch list of a forward pass contains no per-call pointer or scalar: it can be captured once as a hipGraph and
+// replayed for every solver step / every call.
+struct CallBlock {
+    const float* x;     // complex64 [B,1,F,T]
+    const float* y;
+    const float* t;     // float32 [B]
+    float* out;
+    int mode;           // see launch_head
+    float dt;
+};
+int launch_set_call(CallBlock* d_cb, const CallBlock& value, hipStream_t s);
+// d_ts[i * B + b] = ts[i] for i < N (ts: host values, passed to the kernel by value in chunks)
+int launch_fill_times(float* d_ts, const float* ts, int N, int B, hipStream_t s);
+// `cb` != null: x / y / t / out / mode / dt are read from the device-resident call block instead of the arguments
+int launch_pack_input(const float* x_c64, const float* y_c64, int B, int F, int T, float* out4, hipStream_t s,
+                      const CallBlock* cb = nullptr);
 // GaussianFourierProjection(log t): out[b][0:E] = sin, out[b][E:2E] = cos
-int launch_gfp(const float* t, const float* Wf, int B, int E, float* out, hipStream_t s);
+int launch_gfp(const float* t, const float* Wf, int B, int E, float* out, hipStream_t s, const CallBlock* cb = nullptr);
 // out[b][r] = act(sum_k W[r][k] in[b][k] + bias[r]); act: 0 none, 1 SiLU
 int launch_linear(const float* in, int B, int K, const float* W, const float* bias, int R, int act,
                   float* out, int out_stride, hipStream_t s);
@@ -198,7 +215,8 @@ int launch_linear(const float* in, int B, int K, const float* W, const float* bi
 //   mode 1: out = -v           (VFModel.forward)
 //   mode 2: out = x + dt * v   (Euler update  x + VF * (-dt), VF = -v); out may alias x
 int launch_head(const float* pyr4, const float* t, const float* Wout /*[2][4]*/, const float* bout /*[2]*/,
-                int B, int F, int T, int mode, const float* x_c64, float dt, float* out_c64, hipStream_t s);
+                int B, int F, int T, int mode, const float* x_c64, float dt, float* out_c64, hipStream_t s,
+                const CallBlock* cb = nullptr);
 // fused STFT + compression (-> complex64 [B,1,256,Tpad], frames >= T zeroed) and decompression + iSTFT
 int launch_stft_compress(const float* sig, int B, int L, float scale_in, float* out_c64, int T, int Tpad, float factor,
                          float exponent, hipStream_t s);

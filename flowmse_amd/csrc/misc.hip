@@ -15,17 +15,23 @@ static int grid_for(int64_t total) {
 // Replaces (reference): torch.cat([x, y], 1) of VFModel.forward (flowmse/model.py:166) + the real/imag
 // split of NCSNpp.forward (flowmse/backbones/ncsnpp.py:252-254).
 __global__ __launch_bounds__(256) void pack_input_kernel(const float2* __restrict__ x, const float2* __restrict__ y,
-                                                         int64_t n, float4* __restrict__ out) {
+                                                         int64_t n, float4* __restrict__ out,
+                                                         const CallBlock* __restrict__ cb) {
+    if (cb) {
+        x = reinterpret_cast<const float2*>(cb->x);
+        y = reinterpret_cast<const float2*>(cb->y);
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float2 a = x[i], b = y[i];
         out[i] = make_float4(a.x, a.y, b.x, b.y);
     }
 }
 
-int launch_pack_input(const float* x, const float* y, int B, int F, int T, float* out4, hipStream_t s) {
+int launch_pack_input(const float* x, const float* y, int B, int F, int T, float* out4, hipStream_t s,
+                      const CallBlock* cb) {
     const int64_t n = (int64_t)B * F * T;
     hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(n)), dim3(256), 0, s, reinterpret_cast<const float2*>(x),
-                       reinterpret_cast<const float2*>(y), n, reinterpret_cast<float4*>(out4));
+                       reinterpret_cast<const float2*>(y), n, reinterpret_cast<float4*>(out4), cb);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
@@ -35,7 +41,9 @@ int launch_pack_input(const float* x, const float* y, int B, int F, int T, float
 // GaussianFourierProjection.forward (layerspp.py:39-41): x_proj = ((log t * W) * 2) * pi in fp32,
 // out = [sin(x_proj), cos(x_proj)].  log / sin / cos are evaluated in fp64 from the fp32 operands and
 // rounded once, so the result is the correctly rounded fp32 value of the reference's expression.
-__global__ void gfp_kernel(const float* __restrict__ t, const float* __restrict__ Wf, int E, float* __restrict__ out) {
+__global__ void gfp_kernel(const float* __restrict__ t, const float* __restrict__ Wf, int E, float* __restrict__ out,
+                           const CallBlock* __restrict__ cb) {
+    if (cb) t = cb->t;
     const int b = blockIdx.x;
     const float lt = (float)log((double)t[b]);
     for (int j = threadIdx.x; j < E; j += blockDim.x) {
@@ -45,8 +53,8 @@ __global__ void gfp_kernel(const float* __restrict__ t, const float* __restrict_
     }
 }
 
-int launch_gfp(const float* t, const float* Wf, int B, int E, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(gfp_kernel, dim3(B), dim3(128), 0, s, t, Wf, E, out);
+int launch_gfp(const float* t, const float* Wf, int B, int E, float* out, hipStream_t s, const CallBlock* cb) {
+    hipLaunchKernelGGL(gfp_kernel, dim3(B), dim3(128), 0, s, t, Wf, E, out, cb);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
@@ -93,7 +101,15 @@ int launch_linear(const float* in, int B, int K, const float* W, const float* bi
 __global__ __launch_bounds__(256) void head_kernel(const float4* __restrict__ pyr, const float* __restrict__ t,
                                                    const float* __restrict__ Wout, const float* __restrict__ bout,
                                                    int64_t n, int64_t per_sample, int mode,
-                                                   const float2* __restrict__ x, float dt, float2* __restrict__ out) {
+                                                   const float2* __restrict__ x, float dt, float2* __restrict__ out,
+                                                   const CallBlock* __restrict__ cb) {
+    if (cb) {
+        t = cb->t;
+        x = reinterpret_cast<const float2*>(cb->x);
+        out = reinterpret_cast<float2*>(cb->out);
+        mode = cb->mode;
+        dt = cb->dt;
+    }
     const float w00 = Wout[0], w01 = Wout[1], w02 = Wout[2], w03 = Wout[3];
     const float w10 = Wout[4], w11 = Wout[5], w12 = Wout[6], w13 = Wout[7];
     const float b0 = bout[0], b1 = bout[1];
@@ -116,12 +132,39 @@ __global__ __launch_bounds__(256) void head_kernel(const float4* __restrict__ py
 }
 
 int launch_head(const float* pyr4, const float* t, const float* Wout, const float* bout, int B, int F, int T, int mode,
-                const float* x, float dt, float* out, hipStream_t s) {
+                const float* x, float dt, float* out, hipStream_t s, const CallBlock* cb) {
     const int64_t n = (int64_t)B * F * T;
     hipLaunchKernelGGL(head_kernel, dim3(grid_for(n)), dim3(256), 0, s, reinterpret_cast<const float4*>(pyr4), t, Wout,
                        bout, n, (int64_t)F * T, mode, reinterpret_cast<const float2*>(x), dt,
-                       reinterpret_cast<float2*>(out));
+                       reinterpret_cast<float2*>(out), cb);
     FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-call state kept in device memory (see CallBlock in common.h).  The new value travels as a kernel argument,
+// i.e. it is copied at launch time: no host buffer has to outlive the call and nothing synchronises.
+__global__ void set_call_kernel(CallBlock* cb, CallBlock v) { *cb = v; }
+
+int launch_set_call(CallBlock* d_cb, const CallBlock& value, hipStream_t s) {
+    hipLaunchKernelGGL(set_call_kernel, dim3(1), dim3(1), 0, s, d_cb, value);
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+struct TimeChunk { float v[64]; };
+__global__ void fill_times_kernel(float* __restrict__ d_ts, TimeChunk c, int n, int B) {
+    for (int i = threadIdx.x; i < n * B; i += blockDim.x) d_ts[i] = c.v[i / B];
+}
+
+int launch_fill_times(float* d_ts, const float* ts, int N, int B, hipStream_t s) {
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        TimeChunk c;
+        const int n = N - i0 < 64 ? N - i0 : 64;
+        for (int i = 0; i < 64; ++i) c.v[i] = i < n ? ts[i0 + i] : 0.f;
+        hipLaunchKernelGGL(fill_times_kernel, dim3(1), dim3(256), 0, s, d_ts + (size_t)i0 * B, c, n, B);
+        FLOWSE_LAUNCH_CHECK();
+    }
     return OK;
 }
 

@@ -115,27 +115,24 @@ class Arena {
     size_t end_ = 0, peak_ = 0;
 };
 
-struct CallState {            // per-call dynamic arguments read by the plan's closures
-    const float* x = nullptr;
-    const float* y = nullptr;
-    const float* t = nullptr;
-    float* out = nullptr;
-    int mode = 0;
-    float dt = 0.f;
-};
-
 struct Plan {
     int B = 0, F = 0, T = 0;
     size_t ws_bytes = 0;
     std::vector<std::function<int(hipStream_t)>> ops;
     std::vector<std::string> labels;
     std::vector<double> flops, bytes;      // algorithmic work / HBM traffic of each launch
-    std::vector<char> dominant;            // 1 = launches conv3x3_halo_kernel<2,2,2,2,true> (the dominant kernel)
+    std::vector<double> issued;            // FLOPs the matrix cores execute for it (Winograd forms: 1/2 or 2/3 of `flops`)
+    std::vector<char> dominant;            // 1 = a launch of the dominant kernel (the F(4,3) 3x3 conv with fused GroupNorm)
+    // The launch list holds no per-call argument (those live in the handle's device-resident CallBlock), so after one
+    // eager pass it is captured as a hipGraph and replayed: one graph launch per network evaluation.
+    int eager_runs = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
 };
 
 struct ProfAcc {
     int64_t launches = 0;
-    double ms = 0.0, flops = 0.0, bytes = 0.0;
+    double ms = 0.0, flops = 0.0, bytes = 0.0, issued = 0.0;
 };
 
 }  // namespace flowse
@@ -165,15 +162,19 @@ struct flowse_model {
     float* d_ts = nullptr;                 // [N][B] solver times
     size_t d_ts_floats = 0;
     std::map<std::tuple<int, int, int>, Plan> plans;
-    CallState call;
+    CallBlock* d_call = nullptr;           // per-call arguments of the boundary kernels, in device memory
+    int device = -1;                       // HIP device that owns every d_* buffer of this handle
+    bool use_graph = true;                 // FLOWSE_NO_GRAPH=1: always launch eagerly
     // optional in-library profiler (flowse_profile_begin / _end): HIP events around selected launches
     int prof_mode = -1;                    // -1 off, 0 dominant kernel only, 1 every op
     std::vector<hipEvent_t> prof_pool;     // reusable events
     size_t prof_used = 0;
-    struct Pending { int label; hipEvent_t a, b; double flops, bytes; };
+    struct Pending { int label; hipEvent_t a, b; double flops, bytes, issued; };
     std::vector<Pending> prof_pending;
     std::vector<std::string> prof_labels;
     std::map<std::string, int> prof_label_ix;
+    double prof_tot_flops = 0.0, prof_tot_issued = 0.0;    // over every launch between _begin and _end
+    int64_t prof_tot_launches = 0;
 
     float* W(int64_t off) const { return d_w + off; }
     float* A(size_t off) const { return reinterpret_cast<float*>(d_ws + off); }
@@ -482,11 +483,12 @@ struct Builder {
         t.st_nblk = 0;
     }
     void op(const std::string& label, std::function<int(hipStream_t)> f, double flops = 0.0, double bytes = 0.0,
-            bool dominant = false) {
+            bool dominant = false, double issued = -1.0) {
         plan->ops.push_back(std::move(f));
         plan->labels.push_back(label);
         plan->flops.push_back(flops);
         plan->bytes.push_back(bytes);
+        plan->issued.push_back(issued < 0.0 ? flops : issued);
         plan->dominant.push_back(dominant ? 1 : 0);
     }
 
@@ -666,7 +668,8 @@ struct Builder {
         op(full_label, [=](hipStream_t s) {
             const ConvArgs c = make_args();
             return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s, false);
-        }, flops, in_bytes + (ks > 1 ? part_bytes : out_bytes), has_gin && Cout > 64);
+        }, flops, in_bytes + (ks > 1 ? part_bytes : out_bytes), has_gin && Cout > 64,
+           wino_off >= 0 ? flops * (conv_wino_default_f43() ? 0.5 : 2.0 / 3.0) : flops);
         if (ks > 1)
             op("splitk_reduce@" + std::to_string(H) + "x" + std::to_string(Wd), [=](hipStream_t s) { return launch_splitk_reduce(make_args(), s); }, 0.0,
                part_bytes + out_bytes);
@@ -795,7 +798,7 @@ static int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
     const size_t table = bd.M_table_off;
     {
         const int64_t wg = gfp.w_a, w1 = lin1.w_a, b1 = lin1.w_a_b, w2 = lin2.w_a, b2 = lin2.w_a_b;
-        bd.op("gfp", [=](hipStream_t s) { return launch_gfp(M->call.t, M->W(wg), B, nf, M->A(e0), s); });
+        bd.op("gfp", [=](hipStream_t s) { return launch_gfp(nullptr, M->W(wg), B, nf, M->A(e0), s, M->d_call); });
         bd.op("temb_linear1", [=](hipStream_t s) {
             return launch_linear(M->A(e0), B, 2 * nf, M->W(w1), M->W(b1), td, 1, M->A(e1), td, s);
         });
@@ -812,7 +815,7 @@ static int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
     Tn in4 = bd.alloc(F, T, 4);
     {
         const size_t o = in4.off;
-        bd.op("pack_input", [=](hipStream_t s) { return launch_pack_input(M->call.x, M->call.y, B, F, T, M->A(o), s); });
+        bd.op("pack_input", [=](hipStream_t s) { return launch_pack_input(nullptr, nullptr, B, F, T, M->A(o), s, M->d_call); });
     }
     const Module& cin = next();
     std::vector<Tn> hs;
@@ -896,11 +899,36 @@ static int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
     {
         const size_t p = pyr.off;
         bd.op("head", [=](hipStream_t s) {
-            return launch_head(M->A(p), M->call.t, M->W(M->w_out), M->W(M->w_out_b), B, F, T, M->call.mode, M->call.x,
-                               M->call.dt, M->call.out, s);
+            return launch_head(M->A(p), nullptr, M->W(M->w_out), M->W(M->w_out_b), B, F, T, 0, nullptr, 0.f, nullptr, s,
+                               M->d_call);
         });
     }
     plan->ws_bytes = bd.arena.peak();
+    return OK;
+}
+
+static void drop_graph(Plan* p) {
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    p->exec = nullptr;
+    p->graph = nullptr;
+    p->eager_runs = 0;
+}
+
+static void clear_plans(flowse_model* m) {
+    for (auto& kv : m->plans) drop_graph(&kv.second);
+    m->plans.clear();
+}
+
+// every device call of a handle must be made with the handle's device current (the buffers live there)
+static int check_device(const flowse_model* m) {
+    int dev = 0;
+    FLOWSE_HIP(hipGetDevice(&dev));
+    if (m->device >= 0 && dev != m->device) {
+        set_error("model handle is bound to HIP device %d but device %d is current (reload the weights on the new "
+                  "device, or hipSetDevice back)", m->device, dev);
+        return ERR_STATE;
+    }
     return OK;
 }
 
@@ -909,6 +937,7 @@ static int get_plan(flowse_model* m, int B, int F, int T, Plan** out) {
         set_error("weights not loaded: call flowse_model_load_weights first");
         return ERR_STATE;
     }
+    if (const int rc = check_device(m)) return rc;
     auto key = std::make_tuple(B, F, T);
     auto it = m->plans.find(key);
     if (it == m->plans.end()) {
@@ -919,8 +948,9 @@ static int get_plan(flowse_model* m, int B, int F, int T, Plan** out) {
     }
     Plan* p = &it->second;
     if (p->ws_bytes > m->d_ws_bytes) {
-        // growing the workspace: the stream may still be using the old one
+        // growing the workspace: the stream may still be using the old one, and captured graphs point into it
         FLOWSE_HIP(hipDeviceSynchronize());
+        for (auto& kv : m->plans) drop_graph(&kv.second);
         if (m->d_ws) FLOWSE_HIP(hipFree(m->d_ws));
         m->d_ws = nullptr;
         m->d_ws_bytes = 0;
@@ -942,6 +972,13 @@ static int prof_event(flowse_model* m, hipEvent_t* e) {
 }
 
 static int run_plan(flowse_model* m, Plan* p, hipStream_t s) {
+    if (m->prof_mode != -1) {
+        for (size_t i = 0; i < p->ops.size(); ++i) {
+            m->prof_tot_flops += p->flops[i];
+            m->prof_tot_issued += p->issued[i];
+        }
+        m->prof_tot_launches += (int64_t)p->ops.size();
+    }
     for (size_t i = 0; i < p->ops.size(); ++i) {
         const bool prof = m->prof_mode == 1 || (m->prof_mode == 0 && p->dominant[i]);
         flowse_model::Pending pd;
@@ -955,6 +992,7 @@ static int run_plan(flowse_model* m, Plan* p, hipStream_t s) {
             pd.label = it->second;
             pd.flops = p->flops[i];
             pd.bytes = p->bytes[i];
+            pd.issued = p->issued[i];
             int rc = prof_event(m, &pd.a);
             if (rc != OK) return rc;
             rc = prof_event(m, &pd.b);
@@ -969,6 +1007,69 @@ static int run_plan(flowse_model* m, Plan* p, hipStream_t s) {
         }
     }
     return OK;
+}
+
+// One network evaluation.  First call per shape: eager (also performs the one-time per-device kernel attribute
+// setup); second call: the same launch list is captured into a hipGraph; afterwards one hipGraphLaunch per call.
+// Profiling (per-launch events), the NULL stream and FLOWSE_NO_GRAPH=1 keep the eager path.
+static int exec_plan(flowse_model* m, Plan* p, hipStream_t s) {
+    if (!m->use_graph || m->prof_mode != -1 || s == nullptr) return run_plan(m, p, s);
+    if (p->exec) {
+        FLOWSE_HIP(hipGraphLaunch(p->exec, s));
+        return OK;
+    }
+    if (p->eager_runs < 1) {
+        ++p->eager_runs;
+        return run_plan(m, p, s);
+    }
+    FLOWSE_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = run_plan(m, p, s);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc != OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess || !g) {                    // capture refused: stay eager for this plan
+        (void)hipGetLastError();
+        if (g) (void)hipGraphDestroy(g);
+        m->use_graph = false;
+        return run_plan(m, p, s);
+    }
+    hipGraphExec_t ex = nullptr;
+    if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess || !ex) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(g);
+        m->use_graph = false;
+        return run_plan(m, p, s);
+    }
+    p->graph = g;
+    p->exec = ex;
+    FLOWSE_HIP(hipGraphLaunch(p->exec, s));
+    return OK;
+}
+
+static void free_device_state(flowse_model* m) {
+    int cur = 0;
+    const bool sw = m->device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != m->device;
+    if (sw) (void)hipSetDevice(m->device);
+    if (m->device >= 0) (void)hipDeviceSynchronize();
+    clear_plans(m);
+    if (m->d_w) (void)hipFree(m->d_w);
+    if (m->d_ws) (void)hipFree(m->d_ws);
+    if (m->d_ts) (void)hipFree(m->d_ts);
+    if (m->d_wq) (void)hipFree(m->d_wq);
+    if (m->d_wino) (void)hipFree(m->d_wino);
+    if (m->d_call) (void)hipFree(m->d_call);
+    for (hipEvent_t e : m->prof_pool) (void)hipEventDestroy(e);
+    m->prof_pool.clear();
+    m->prof_used = 0;
+    m->d_w = nullptr; m->d_ws = nullptr; m->d_ts = nullptr; m->d_wino = nullptr; m->d_call = nullptr;
+    m->d_wq = nullptr;
+    m->d_w_numel = m->d_wq_numel = m->d_wino_numel = 0;
+    m->d_ws_bytes = m->d_ts_floats = 0;
+    m->device = -1;
+    if (sw) (void)hipSetDevice(cur);
 }
 
 }  // namespace flowse
@@ -995,6 +1096,7 @@ int flowse_model_create(const flowse_config* cfg, flowse_model** out) {
     }
     flowse_model* m = new flowse_model();
     m->cfg = *cfg;
+    m->use_graph = getenv("FLOWSE_NO_GRAPH") == nullptr;
     const int rc = build_structure(m);
     if (rc != OK) {
         delete m;
@@ -1006,12 +1108,7 @@ int flowse_model_create(const flowse_config* cfg, flowse_model** out) {
 
 void flowse_model_destroy(flowse_model* m) {
     if (!m) return;
-    if (m->d_w) (void)hipFree(m->d_w);
-    if (m->d_ws) (void)hipFree(m->d_ws);
-    if (m->d_ts) (void)hipFree(m->d_ts);
-    if (m->d_wq) (void)hipFree(m->d_wq);
-    if (m->d_wino) (void)hipFree(m->d_wino);
-    for (hipEvent_t e : m->prof_pool) (void)hipEventDestroy(e);
+    free_device_state(m);
     delete m;
 }
 
@@ -1044,13 +1141,15 @@ int flowse_model_set_precision(flowse_model* m, int mode) {
     }
     if (mode != m->precision) {
         m->precision = mode;
-        m->plans.clear();
         if (m->d_w) {            // weights must be re-uploaded so that the bf16 planes match the mode
+            if (const int rc = check_device(m)) return rc;
             FLOWSE_HIP(hipDeviceSynchronize());
+            clear_plans(m);
             FLOWSE_HIP(hipFree(m->d_w));
             m->d_w = nullptr;
             m->d_w_numel = 0;
         }
+        clear_plans(m);
     }
     return OK;
 }
@@ -1068,7 +1167,13 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
     Packer pk;
     const int rc = pack_weights(m, blob, pk);
     if (rc != OK) return rc;
+    int dev = 0;
+    FLOWSE_HIP(hipGetDevice(&dev));
+    if (m->device >= 0 && m->device != dev) free_device_state(m);      // the handle moves to the current device
+    m->device = dev;
     FLOWSE_HIP(hipDeviceSynchronize());
+    clear_plans(m);          // closures captured weight offsets of the previous packing
+    if (!m->d_call) FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_call), sizeof(CallBlock)));
     if (m->d_w && m->d_w_numel < (int64_t)pk.host.size()) {
         FLOWSE_HIP(hipFree(m->d_w));
         m->d_w = nullptr;
@@ -1129,7 +1234,6 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
         if (!q.empty())
             FLOWSE_HIP(hipMemcpy(m->d_wq, q.data(), q.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
-    m->plans.clear();        // closures captured weight offsets of the previous packing
     return OK;
 }
 
@@ -1154,13 +1258,11 @@ int flowse_vf_forward(flowse_model* m, const void* x, const void* y, const float
     Plan* p = nullptr;
     int rc = get_plan(m, B, F, T, &p);
     if (rc != OK) return rc;
-    m->call.x = static_cast<const float*>(x);
-    m->call.y = static_cast<const float*>(y);
-    m->call.t = t;
-    m->call.out = static_cast<float*>(out);
-    m->call.mode = mode;
-    m->call.dt = 0.f;
-    return run_plan(m, p, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    CallBlock cb{static_cast<const float*>(x), static_cast<const float*>(y), t, static_cast<float*>(out), mode, 0.f};
+    rc = launch_set_call(m->d_call, cb, s);
+    if (rc != OK) return rc;
+    return exec_plan(m, p, s);
 }
 
 int flowse_prior_sample(const void* y, const void* z, float sigma, void* x_out, int64_t numel_complex, void* stream) {
@@ -1194,19 +1296,15 @@ int flowse_euler_sample(flowse_model* m, void* x_inout, const void* y, const flo
         FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_ts), need * sizeof(float)));
         m->d_ts_floats = need;
     }
-    std::vector<float> host(need);
-    for (int i = 0; i < N; ++i)
-        for (int b = 0; b < B; ++b) host[(size_t)i * B + b] = ts[i];   // vec_t = ones(B) * t, sampling/__init__.py:55
-    // pageable source: the runtime stages the copy before returning, so `host` may die at scope exit
-    FLOWSE_HIP(hipMemcpyAsync(m->d_ts, host.data(), need * sizeof(float), hipMemcpyHostToDevice, s));
+    // vec_t = ones(B) * t (sampling/__init__.py:55), written on the device by a kernel that receives the times by value
+    rc = launch_fill_times(m->d_ts, ts, N, B, s);
+    if (rc != OK) return rc;
     for (int i = 0; i < N; ++i) {
-        m->call.x = static_cast<const float*>(x_inout);
-        m->call.y = static_cast<const float*>(y);
-        m->call.t = m->d_ts + (size_t)i * B;
-        m->call.out = static_cast<float*>(x_inout);
-        m->call.mode = 2;
-        m->call.dt = dts[i];
-        rc = run_plan(m, p, s);
+        CallBlock cb{static_cast<const float*>(x_inout), static_cast<const float*>(y), m->d_ts + (size_t)i * B,
+                     static_cast<float*>(x_inout), 2, dts[i]};
+        rc = launch_set_call(m->d_call, cb, s);
+        if (rc != OK) return rc;
+        rc = exec_plan(m, p, s);
         if (rc != OK) return rc;
     }
     return OK;
@@ -1242,6 +1340,8 @@ int flowse_profile_begin(flowse_model* m, int mode) {
     m->prof_pending.clear();
     m->prof_labels.clear();
     m->prof_label_ix.clear();
+    m->prof_tot_flops = m->prof_tot_issued = 0.0;
+    m->prof_tot_launches = 0;
     return OK;
 }
 
@@ -1261,15 +1361,24 @@ int flowse_profile_end(flowse_model* m, char* json, int cap) {
         a.ms += ms;
         a.flops += pd.flops;
         a.bytes += pd.bytes;
+        a.issued += pd.issued;
     }
     m->prof_pending.clear();
     m->prof_used = 0;
     std::string out = "{";
     for (size_t i = 0; i < acc.size(); ++i) {
-        char buf[256];
-        snprintf(buf, sizeof(buf), "%s\"%s\": {\"launches\": %lld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+        char buf[384];
+        snprintf(buf, sizeof(buf),
+                 "%s\"%s\": {\"launches\": %lld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e, \"issued\": %.6e}",
                  i ? ", " : "", m->prof_labels[i].c_str(), (long long)acc[i].launches, acc[i].ms, acc[i].flops,
-                 acc[i].bytes);
+                 acc[i].bytes, acc[i].issued);
+        out += buf;
+    }
+    {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s\"_all_launches\": {\"launches\": %lld, \"ms\": 0, \"flops\": %.6e, \"bytes\": 0, "
+                 "\"issued\": %.6e}", acc.empty() ? "" : ", ", (long long)m->prof_tot_launches, m->prof_tot_flops,
+                 m->prof_tot_issued);
         out += buf;
     }
     out += "}";

@@ -7,6 +7,8 @@
 // (SURVEY.md section 8(f), rank 1).  O(n_fft^2) direct DFTs with an exact 510-entry twiddle table: 0.13 MFLOP per
 // frame -- microseconds per utterance, no FFT library, no intermediate tensors.
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -15,13 +17,20 @@ namespace flowse {
 
 constexpr int NFFT = 510, HOP = 128, NBIN = 256, PADC = NFFT / 2;   // 255 samples of centre padding
 
-struct SpecTables {
-    float* d = nullptr;      // [3][NFFT]: window, cos(2 pi k / NFFT), sin(2 pi k / NFFT)
-};
-static SpecTables g_tab;
+// [3][NFFT]: window, cos(2 pi k / NFFT), sin(2 pi k / NFFT) -- one copy per device, created under a lock on the
+// first call made with that device current (a pointer of one device must never be handed to another's kernels)
+static std::mutex g_tab_mu;
+static std::map<int, float*> g_tab_of_device;
 
-static int ensure_tables() {
-    if (g_tab.d) return OK;
+static int ensure_tables(float** out) {
+    int dev = 0;
+    FLOWSE_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_tab_mu);
+    auto it = g_tab_of_device.find(dev);
+    if (it != g_tab_of_device.end()) {
+        *out = it->second;
+        return OK;
+    }
     std::vector<float> h(3 * NFFT);
     for (int k = 0; k < NFFT; ++k) {
         const double a = 2.0 * M_PI * (double)k / (double)NFFT;
@@ -29,8 +38,11 @@ static int ensure_tables() {
         h[NFFT + k] = (float)cos(a);
         h[2 * NFFT + k] = (float)sin(a);
     }
-    FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&g_tab.d), h.size() * sizeof(float)));
-    FLOWSE_HIP(hipMemcpy(g_tab.d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    float* d = nullptr;
+    FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&d), h.size() * sizeof(float)));
+    FLOWSE_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    g_tab_of_device[dev] = d;
+    *out = d;
     return OK;
 }
 
@@ -143,9 +155,10 @@ int launch_stft_compress(const float* sig, int B, int L, float scale_in, float* 
         set_error("stft: need L > %d, T == L / %d + 1 (got L=%d T=%d Tpad=%d B=%d)", PADC, HOP, L, T, Tpad, B);
         return ERR_SHAPE;
     }
-    int rc = ensure_tables();
+    float* tab = nullptr;
+    int rc = ensure_tables(&tab);
     if (rc != OK) return rc;
-    hipLaunchKernelGGL(stft_compress_kernel, dim3(Tpad, B), dim3(256), 0, s, sig, L, scale_in, g_tab.d,
+    hipLaunchKernelGGL(stft_compress_kernel, dim3(Tpad, B), dim3(256), 0, s, sig, L, scale_in, tab,
                        reinterpret_cast<float2*>(out_c64), T, Tpad, factor, exponent);
     FLOWSE_LAUNCH_CHECK();
     return OK;
@@ -157,10 +170,11 @@ int launch_istft_decompress(const float* spec_c64, int B, int T, int Tpad, float
         set_error("istft: bad shape T=%d Tpad=%d Lout=%d B=%d", T, Tpad, Lout, B);
         return ERR_SHAPE;
     }
-    int rc = ensure_tables();
+    float* tab = nullptr;
+    int rc = ensure_tables(&tab);
     if (rc != OK) return rc;
     hipLaunchKernelGGL(istft_decompress_kernel, dim3((Lout + HOP - 1) / HOP, B), dim3(256), 0, s,
-                       reinterpret_cast<const float2*>(spec_c64), T, Tpad, factor, exponent, g_tab.d, out, Lout,
+                       reinterpret_cast<const float2*>(spec_c64), T, Tpad, factor, exponent, tab, out, Lout,
                        scale_out);
     FLOWSE_LAUNCH_CHECK();
     return OK;

@@ -69,16 +69,35 @@ def enhance_batch(model, ys, N=5, T_rev=1.0, t_eps=0.03, odesolver="euler"):
     a time, evaluate.py:97; trajectories are independent, so batching changes nothing but throughput).
     ys: list of float tensors [1, samples_i] on the target device.  Returns a list of numpy waveforms."""
     norms = [y.abs().max().item() for y in ys]
-    specs = [pad_spec(torch.unsqueeze(model._forward_transform(model._stft(y / n)), 0)) for y, n in zip(ys, norms)]
+    dm = model.data_module
+    fused = hasattr(dm, "fused_ok") and all(dm.fused_ok(y) for y in ys)
+    if fused:                      # STFT + compression + frame padding: one HIP kernel per utterance
+        specs = [dm.analyze(y, 1.0 / n) for y, n in zip(ys, norms)]
+    else:
+        specs = [pad_spec(torch.unsqueeze(model._forward_transform(model._stft(y / n)), 0)) for y, n in zip(ys, norms)]
     Y = torch.cat(specs, dim=0)
     sample, _ = get_white_box_solver(odesolver, model.ode, model, Y=Y, Y_prior=Y, T_rev=T_rev, t_eps=t_eps, N=N)()
+    if fused:                      # decompression + iSTFT + rescale: one HIP kernel per utterance
+        return [dm.synthesize(sample[i:i + 1], y.size(1), n).squeeze().cpu().numpy()
+                for i, (y, n) in enumerate(zip(ys, norms))]
     return [(model.to_audio(sample[i, 0], y.size(1)) * n).squeeze().cpu().numpy()
             for i, (y, n) in enumerate(zip(ys, norms))]
 
 
 def _write_wav(path, x, sr=16000):
+    """16-bit PCM WAV like the reference's ``soundfile.write(path, x_hat, 16000)`` (evaluate.py:147; libsndfile's
+    default subtype for .wav is PCM_16, float samples scaled by 0x7FFF and rounded to nearest).  soundfile itself is
+    used when importable, so output trees diff cleanly against the reference's."""
+    x = np.asarray(x, dtype=np.float32)
+    try:
+        import soundfile
+        soundfile.write(path, x, sr)
+        return
+    except ImportError:
+        pass
     from scipy.io import wavfile
-    wavfile.write(path, sr, np.asarray(x, dtype=np.float32))
+    pcm = np.clip(np.rint(x.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+    wavfile.write(path, sr, pcm)
 
 
 def _synthetic_pairs(n, seconds=2.0, sr=16000, seed=0):
@@ -102,11 +121,15 @@ def main(argv=None):
     ap.add_argument("--folder_destination", type=str, required=True)
     ap.add_argument("--ckpt", type=str, default=None)
     ap.add_argument("--N", type=int, default=5)
+    ap.add_argument("--N_mid", type=int, default=0, help="accepted for command-line compatibility (evaluate.py:42: "
+                                                         "'not related to FlowSE'); must be 0")
     ap.add_argument("--synthetic", type=int, default=0, help="run on this many synthetic pairs with synthetic weights")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16", "fp16"])
     ap.add_argument("--batch", type=int, default=1,
                     help="enhance up to this many utterances of equal padded length per sampler call (1 = reference behaviour)")
     args = ap.parse_args(argv)
+    if args.N_mid != 0:
+        raise ValueError("N_mid should be 0.")          # evaluate.py:124-125
 
     from flowmse_amd.model import VFModel
     if args.synthetic:

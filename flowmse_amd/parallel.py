@@ -79,14 +79,20 @@ def gather_spectrograms(local, local_ids, n_total, group=None):
     return out
 
 
-def enhance_sharded(sample_fn, specs, max_batch=8, group=None, pad_multiple=64):
+def enhance_sharded(sample_fn, specs, max_batch=8, group=None, pad_multiple=64, keep_padding=False):
     """Enhance a ragged set of utterances data-parallel over the ranks of `group` (BASELINE config 4).
 
     specs: list of complex64 spectrograms [F, T_i] (every rank holds the same list, or at least the entries of its
     own shard); sample_fn(Y, ids) -> X maps a zero-padded batch Y [b,1,F,T] of equal padded length to the enhanced
     batch (ids = global utterance indices of the rows, e.g. to pick reproducible noise).  Utterances are dealt to
-    ranks by padded length (LPT), batched by equal padded length, enhanced, cropped back to T_i and gathered to
-    rank 0 with ONE exchange at the very end.  Returns the list of enhanced [F, T_i] tensors on rank 0, None elsewhere.
+    ranks by padded length (LPT), batched by equal padded length, enhanced and gathered to rank 0 with ONE exchange at
+    the very end.  Returns on rank 0 the list of enhanced spectrograms, None elsewhere:
+
+    * keep_padding=False: each cropped back to its own [F, T_i] (the spectrogram of the utterance);
+    * keep_padding=True: the whole padded [F, Tpad_i] sample.  This is what the reference feeds to the iSTFT
+      (evaluate.py:132 ``model.to_audio(sample, T_orig)`` on the padded sample): the zero-padded frames are no longer
+      zero after enhancement and, through the overlap-add and the window envelope, reach the last ~127 samples of the
+      waveform.  Use it whenever waveforms must equal the per-utterance path's (``SpecTransform.synthesize``).
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -98,6 +104,6 @@ def enhance_sharded(sample_fn, specs, max_batch=8, group=None, pad_multiple=64):
         Y = torch.stack([torch.nn.functional.pad(specs[i], (0, T - true_len[i])) for i in ids])[:, None]
         X = sample_fn(Y.contiguous(), ids)
         for row, i in enumerate(ids):
-            out_local.append(X[row, 0, :, :true_len[i]])
+            out_local.append(X[row, 0] if keep_padding else X[row, 0, :, :true_len[i]])
             ids_local.append(i)
     return gather_spectrograms(out_local, ids_local, len(specs), group=group)

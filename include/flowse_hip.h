@@ -82,7 +82,11 @@ int flowse_model_param_info(const flowse_model* m, int index, char* name, int na
 int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel);
 
 /* Matrix-core operand precision of the large 3x3 ResBlock convolutions (call BEFORE flowse_model_load_weights; a
- * change drops the uploaded weights).  0 (default): fp32 MFMA, bit-exact fp32 products.  1 "bf16x3": operands split
+ * change drops the uploaded weights).  0 (default): every operand, product and accumulation is fp32
+ * (v_mfma_f32_32x32x2_f32).  3x3 convolutions with Cin % 32 == 0 and Cout % 64 == 0 on images the LDS-halo kernel
+ * covers are evaluated in the F(4,3) Winograd form along the filter's vertical axis (half the multiplies; transformed
+ * fp32 operands, rounding error ~3x the direct sum's, 4e-7..2e-6 rel-L2 per layer); FLOWSE_WINOGRAD=f23 selects the
+ * F(2,3) form, FLOWSE_NO_WINOGRAD=1 the direct form, whose result is bit for bit an fmaf chain.  1 "bf16x3": operands split
  * x = hi + lo in bf16, products hi*hi + hi*lo + lo*hi accumulated in fp32 (fp32-class accuracy, ~1e-5).  2 "bf16":
  * plain bf16 operands (BASELINE config 3).  3 "fp16": IEEE half operands (BASELINE config 5).  Accumulation,
  * GroupNorm statistics, residuals and activations stay fp32 in every mode. */
@@ -106,7 +110,10 @@ int flowse_prior_sample(const void* y, const void* z, float sigma, void* x_out, 
 /* N Euler steps in place on x (ode_solver loop, flowmse/sampling/__init__.py:45-57, with
  * EulerODEsolver.update_fn, sampling/odesolvers.py:42-47):  for i: x <- x + VF(x, ts[i], y) * (-dts[i]).
  * ts, dts: HOST float32 arrays of length N (the caller reproduces torch.linspace and the step rule, including
- * the final step dts[N-1] = ts[N-1]).  No host synchronisation. */
+ * the final step dts[N-1] = ts[N-1]); they are consumed before the call returns (passed to the device as kernel
+ * arguments, no asynchronous host copy).  No host synchronisation.  Each network evaluation is one hipGraph launch
+ * (the launch list of a shape is captured on its second use; FLOWSE_NO_GRAPH=1, the NULL stream and an active
+ * flowse_profile_begin keep plain launches). */
 int flowse_euler_sample(flowse_model* m, void* x_inout, const void* y, const float* ts, const float* dts, int N,
                         int B, int F, int T, void* stream);
 /* One generic explicit update from a caller-held slope: x <- x + dt * k (complex64 as float pairs). */
@@ -118,7 +125,9 @@ int flowse_axpy(const void* x, const void* k, float dt, void* out, int64_t numel
  * center=True (reflect): T = L / 128 + 1 frames, frames T..Tpad-1 are zero.  spec_fwd = factor * |z|^exponent *
  * exp(j arg z) (transform_type "exponent"; exponent 1 = plain scaling).
  * flowse_istft_decompress: the inverse chain istft(spec_back(spec), length = Lout) * scale_out
- * (data_module.py:164-175,203-205; model.py:190-191) on the first T frames of the padded spectrogram. */
+ * (data_module.py:164-175,203-205; model.py:190-191) over frames 0..T-1 of a spectrogram whose frame pitch is Tpad.
+ * The reference runs the iSTFT over ALL frames of the padded sample (model.py:190-191, evaluate.py:132), i.e.
+ * T == Tpad there: the zero-padded frames are no longer zero after enhancement and reach the last ~127 samples. */
 int flowse_stft_compress(const float* sig, int B, int L, float scale_in, void* out_c64, int T, int Tpad, float factor,
                          float exponent, void* stream);
 int flowse_istft_decompress(const void* spec_c64, int B, int T, int Tpad, float factor, float exponent, float* out,
@@ -126,10 +135,13 @@ int flowse_istft_decompress(const void* spec_c64, int B, int T, int Tpad, float 
 
 /* ---- in-library kernel timing (used by bench.py for the live roofline figure) -------------------------
  * Between _begin and _end every selected launch of this handle is bracketed by HIP events on the launch
- * stream.  mode 0: only launches of the dominant kernel (conv3x3_halo_kernel<2,2,2,2,true>: 3x3 conv, 128x128
- * tile, fused GroupNorm+SiLU input), reported under the key "conv3x3_halo_gn_128x128"; mode 1: every launch, keyed by op label.  _end synchronises on the recorded events
- * and writes a JSON object {label: {"launches", "ms", "flops", "bytes"}} (algorithmic flops / bytes of the
- * bracketed launches) into `json`. */
+ * stream (and the handle launches eagerly instead of replaying its hipGraph).  mode 0: only launches of the dominant
+ * kernel -- the 3x3 ResBlock convolutions with fused GroupNorm+SiLU input and Cout > 64 (conv3x3_f43_kernel<2> by
+ * default) -- reported under the key "dominant_conv3x3"; mode 1: every launch, keyed by op label.  _end synchronises
+ * on the recorded events and writes a JSON object {label: {"launches", "ms", "flops", "bytes", "issued"}} into `json`:
+ * algorithmic flops / bytes of the bracketed launches, and `issued` = the flops the matrix cores execute for them
+ * (Winograd forms issue 1/2 or 2/3 of the algorithmic direct-convolution flops).  The extra key "_all_launches"
+ * totals launches / flops / issued over EVERY launch made between _begin and _end (no timing). */
 int flowse_profile_begin(flowse_model* m, int mode);
 int flowse_profile_end(flowse_model* m, char* json, int cap);
 

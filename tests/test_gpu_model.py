@@ -156,16 +156,17 @@ def test_full_sampler_vs_oracle_T256(full):
     assert err < TOL
 
 
-@pytest.mark.parametrize("B,T", [(1, 64), (1, 192), (3, 128)])
+@pytest.mark.parametrize("B,T", [(1, 64), (1, 192), (3, 128), (8, 64)])
 def test_full_forward_shapes_vs_oracle(full, B, T):
-    """Smallest legal utterance, a frame count that is not a power of two (W = 192, 96, 48, 24, 12, 6, 3) and an
-    odd batch, with per-sample times spanning the grid ends (t = 0.03 amplifies the head by 33x)."""
+    """Smallest legal utterance, a frame count that is not a power of two (W = 192, 96, 48, 24, 12, 6, 3), an odd
+    batch, and the headline batch size B = 8 (its own kernel dispatch: Winograd plan / split slices are chosen from
+    B*H*W), with per-sample times spanning the grid ends (t = 0.03 amplifies the head by 33x)."""
     from oracle import ncsnpp_oracle as O
     tb = C.param_tables()["full"]
     w = C.synth_weights(tb["names"], tb["shapes"])
     x = C.c64(synth.complex_normal(21, T, (B, 1, 256, T), 0.5))
     y = C.c64(synth.synth_spectrogram(40 + T, B, 256, T))
-    t = torch.tensor([0.03, 1.0, 0.515][:B])
+    t = torch.tensor([0.03, 1.0, 0.515, 0.2725, 0.7575, 0.1, 0.9, 0.4][:B])
     ref = O.ncsnpp_forward(w, O.make_cfg(), torch.cat([x, y], 1), t)
     got = full.dnn(torch.cat([x, y], 1).cuda(), t.cuda())
     err = C.rel_l2(got.cpu(), ref)
@@ -303,11 +304,62 @@ def test_enhance_sharded_ragged_matches_per_utterance(tiny):
         return get_white_box_solver("euler", tiny.ode, tiny, Y=Y, N=3, z=z)()[0]
 
     out = enhance_sharded(sample_fn, specs, max_batch=4)
+    padded = enhance_sharded(sample_fn, specs, max_batch=4, keep_padding=True)
     for i, s in enumerate(specs):
         Y = pad_spec(s[None, None])
-        ref = get_white_box_solver("euler", tiny.ode, tiny, Y=Y, N=3, z=noise(i, Y.shape))()[0][0, 0, :, :lens[i]]
+        ref = get_white_box_solver("euler", tiny.ode, tiny, Y=Y, N=3, z=noise(i, Y.shape))()[0][0, 0]
         assert out[i].shape == s.shape
-        assert C.rel_l2(out[i], ref.cpu()) < 1e-5
+        assert C.rel_l2(out[i], ref[:, :lens[i]].cpu()) < 1e-5
+        # keep_padding: the whole padded sample, i.e. what the reference hands to the iSTFT (evaluate.py:132)
+        assert padded[i].shape == ref.shape and C.rel_l2(padded[i], ref.cpu()) < 1e-5
+
+
+def test_graph_replay_equals_eager_launches(tiny):
+    """A shape's launch list is captured as a hipGraph on its second use: replays must be bit-identical to the eager
+    passes (same kernels, same order), for the vector field and for the fused sampler with changing t / dt."""
+    from flowmse_amd.sampling import get_white_box_solver
+    xt, y, z = C.tiny_inputs()
+    X, Y, Z = xt.cuda(), y.cuda(), z.cuda()
+    outs = [tiny(X, torch.tensor([0.03, 1.0], device="cuda"), Y).clone() for _ in range(4)]   # eager, capture, replay x2
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    other = tiny(X, torch.tensor([0.5, 0.2], device="cuda"), Y)                                 # replay with new t
+    assert not torch.equal(other, outs[0])
+    samples = [get_white_box_solver("euler", tiny.ode, tiny, Y=Y, N=4, z=Z)()[0].clone() for _ in range(3)]
+    assert torch.equal(samples[0], samples[1]) and torch.equal(samples[0], samples[2])
+    g = C.gold("tiny_sampler")
+    got = get_white_box_solver("euler", tiny.ode, tiny, Y=Y, N=5, z=Z)()[0]
+    assert C.rel_l2(got.cpu(), g["x_N5"]) < TIGHT
+
+
+@pytest.mark.timeout(900)
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun) must run TWO ranks and say so (it used to measure one GPU silently).
+    With two visible devices: one rank per device over RCCL.  On a one-GPU box: both ranks on device 0 through the
+    FLOWSE_BENCH_SHARE_GPU hook with gloo (RCCL cannot put two ranks on one device)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    two = torch.cuda.device_count() >= 2
+    if not two:
+        env["FLOWSE_BENCH_SHARE_GPU"] = "1"
+        env["FLOWSE_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "1",
+           "--frames", "64", "--no-cpu-baseline", "--no-alt"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["per_rank_ms_per_step"]) == 2 and out["value"] > 0
+    assert out["config"]["global_batch"] == 2
+    assert out["config"]["collective_backend"] == ("nccl" if two else "gloo")
+    if not two:                              # without the hook the same command must refuse, not measure one GPU
+        env2 = {k: v for k, v in os.environ.items() if not k.startswith("FLOWSE_BENCH")}
+        r2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=800)
+        assert r2.returncode != 0 and "visible devices" in (r2.stderr + r2.stdout)
 
 
 @pytest.mark.timeout(600)
