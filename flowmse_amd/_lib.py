@@ -44,6 +44,8 @@ SIGNATURES = {
     "flowse_device_count": (_i, []),
     "flowse_model_create": (_i, [C.POINTER(flowse_config), C.POINTER(_vp)]),
     "flowse_model_destroy": (None, [_vp]),
+    "flowse_block_create": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "flowse_block_forward": (_i, [_vp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "flowse_model_num_params": (_i, [_vp]),
     "flowse_model_num_modules": (_i, [_vp]),
     "flowse_model_blob_numel": (_i64, [_vp]),

@@ -165,6 +165,12 @@ struct flowse_model {
     CallBlock* d_call = nullptr;           // per-call arguments of the boundary kernels, in device memory
     int device = -1;                       // HIP device that owns every d_* buffer of this handle
     bool use_graph = true;                 // FLOWSE_NO_GRAPH=1: always launch eagerly
+    // single-module handles (flowse_block_create): one ResnetBlockBigGANpp / AttnBlockpp / Combine behind the same
+    // weight packer, plan builder and kernels as the full network -- unit parity against the reference's modules
+    int block_kind = -1;                   // -1: full network; else FLOWSE_BLOCK_*
+    struct BlockCall { const float* in1 = nullptr; const float* in2 = nullptr; const float* temb_act = nullptr;
+                       float* out = nullptr; } bcall;
+    std::map<std::tuple<int, int, int, int>, Plan> block_plans;      // (B, H, W, C1)
     // optional in-library profiler (flowse_profile_begin / _end): HIP events around selected launches
     int prof_mode = -1;                    // -1 off, 0 dominant kernel only, 1 every op
     std::vector<hipEvent_t> prof_pool;     // reusable events
@@ -384,8 +390,10 @@ static int pack_weights(flowse_model* m, const float* blob, Packer& pk) {
     const int td = m->temb_dim;
     m->w_dense = pk.put((int64_t)rows * td);
     m->w_dense_b = pk.put(rows);
-    m->w_out = pack_copy(pk, P(m->out_w_p), 8);
-    m->w_out_b = pack_copy(pk, P(m->out_w_p + 1), 2);
+    if (m->block_kind < 0) {
+        m->w_out = pack_copy(pk, P(m->out_w_p), 8);
+        m->w_out_b = pack_copy(pk, P(m->out_w_p + 1), 2);
+    }
     for (auto& mod : m->mods) {
         const int p = mod.p0, ci = mod.in_ch, co = mod.out_ch;
         switch (mod.kind) {
@@ -918,6 +926,7 @@ static void drop_graph(Plan* p) {
 static void clear_plans(flowse_model* m) {
     for (auto& kv : m->plans) drop_graph(&kv.second);
     m->plans.clear();
+    m->block_plans.clear();
 }
 
 // every device call of a handle must be made with the handle's device current (the buffers live there)
@@ -1049,6 +1058,61 @@ static int exec_plan(flowse_model* m, Plan* p, hipStream_t s) {
     return OK;
 }
 
+// Plan of a single-module handle: inputs are copied into the arena, the module runs exactly as inside the network
+// (Builder::resblock / attn / conv), the result is copied out.
+static int build_block_plan(flowse_model* m, Plan* plan, int B, int H, int W, int C1) {
+    const Module& mod = m->mods[0];
+    const bool combine = mod.kind == M_COMBINE;
+    const int C2 = combine ? mod.out_ch : mod.in_ch - C1;
+    if (B < 1 || H < 1 || W < 1 || C1 < 4 || (C1 & 3) || C2 < 0 || (C2 & 3) || (combine && C1 != 4) ||
+        (mod.kind == M_ATTN && C2 != 0) || ((mod.up || mod.down) && C2 != 0) || (mod.down && ((H | W) & 1))) {
+        set_error("flowse_block_forward: bad shape B=%d H=%d W=%d C1=%d for a module with in_ch=%d", B, H, W, C1,
+                  mod.in_ch);
+        return ERR_SHAPE;
+    }
+    plan->B = B; plan->F = H; plan->T = W;
+    Builder bd;
+    bd.m = m;
+    bd.plan = plan;
+    bd.B = B;
+    flowse_model* M = m;
+    const int td = m->temb_dim;
+    Tn x1 = bd.alloc(H, W, C1), x2;
+    if (C2 > 0) x2 = bd.alloc(H, W, C2);
+    {
+        const size_t o1 = x1.off, o2 = x2.off, n1 = x1.bytes(), n2 = C2 > 0 ? x2.bytes() : 0;
+        bd.op("block_in", [=](hipStream_t s) {
+            FLOWSE_HIP(hipMemcpyAsync(M->A(o1), M->bcall.in1, n1, hipMemcpyDeviceToDevice, s));
+            if (n2) FLOWSE_HIP(hipMemcpyAsync(M->A(o2), M->bcall.in2, n2, hipMemcpyDeviceToDevice, s));
+            return (int)OK;
+        });
+    }
+    Tn out;
+    if (mod.kind == M_RESBLOCK) {
+        bd.M_table_off = bd.arena.alloc((size_t)B * m->dense_rows * 4);
+        const size_t table = bd.M_table_off;
+        bd.op("dense_table", [=](hipStream_t s) {          // Dense_0(act(temb)) + Conv_0.bias (layerspp.py:262-263)
+            return launch_linear(M->bcall.temb_act, B, td, M->W(M->w_dense), M->W(M->w_dense_b), M->dense_rows, 0,
+                                 M->A(table), M->dense_rows, s);
+        });
+        out = bd.resblock(mod, x1, C2 > 0 ? &x2 : nullptr);
+    } else if (mod.kind == M_ATTN) {
+        out = bd.attn(mod, x1);
+    } else {                                               // Combine: conv1x1(x) + y (layerspp.py:55-59)
+        bd.conv("combine_1x1", x1, nullptr, mod.w_a, mod.w_a_b, -1, mod.out_ch, 1, &x2, 1.f, true, true);
+        out = x2;
+    }
+    {
+        const size_t o = out.off, n = out.bytes();
+        bd.op("block_out", [=](hipStream_t s) {
+            FLOWSE_HIP(hipMemcpyAsync(M->bcall.out, M->A(o), n, hipMemcpyDeviceToDevice, s));
+            return (int)OK;
+        });
+    }
+    plan->ws_bytes = bd.arena.peak();
+    return OK;
+}
+
 static void free_device_state(flowse_model* m) {
     int cur = 0;
     const bool sw = m->device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != m->device;
@@ -1110,6 +1174,62 @@ void flowse_model_destroy(flowse_model* m) {
     if (!m) return;
     free_device_state(m);
     delete m;
+}
+
+int flowse_block_create(int kind, int in_ch, int out_ch, int up, int down, int temb_dim, flowse_model** out) {
+    if (!out || kind < FLOWSE_BLOCK_RESNET || kind > FLOWSE_BLOCK_COMBINE || in_ch < 4 || (in_ch & 3) || out_ch < 4 ||
+        (out_ch & 3) || (up && down) || (kind == FLOWSE_BLOCK_RESNET && temb_dim < 1) ||
+        (kind == FLOWSE_BLOCK_ATTN && in_ch != out_ch) || (kind == FLOWSE_BLOCK_COMBINE && in_ch != 4)) {
+        set_error("flowse_block_create: bad argument (kind=%d in_ch=%d out_ch=%d up=%d down=%d temb_dim=%d)", kind, in_ch,
+                  out_ch, up, down, temb_dim);
+        return ERR_ARG;
+    }
+    flowse_model* m = new flowse_model();
+    memset(&m->cfg, 0, sizeof(m->cfg));
+    m->use_graph = false;
+    m->block_kind = kind;
+    m->temb_dim = temb_dim;
+    if (kind == FLOWSE_BLOCK_RESNET) add_module(m, resblock(in_ch, out_ch, up != 0, down != 0));
+    else add_module(m, simple(kind == FLOWSE_BLOCK_ATTN ? M_ATTN : M_COMBINE, in_ch, out_ch));
+    *out = m;
+    return OK;
+}
+
+int flowse_block_forward(flowse_model* m, const float* in1, int C1, const float* in2, const float* temb_act, float* out,
+                         int B, int H, int W, void* stream) {
+    if (!m || m->block_kind < 0 || !in1 || !out || (m->block_kind == FLOWSE_BLOCK_RESNET && !temb_act) ||
+        (m->block_kind == FLOWSE_BLOCK_COMBINE && !in2)) {
+        set_error("flowse_block_forward: bad argument (not a block handle, or a required pointer is null)");
+        return ERR_ARG;
+    }
+    if (!m->d_w) {
+        set_error("weights not loaded: call flowse_model_load_weights first");
+        return ERR_STATE;
+    }
+    if (const int rc = check_device(m)) return rc;
+    if (!in2 && m->block_kind == FLOWSE_BLOCK_RESNET) C1 = m->mods[0].in_ch;
+    auto key = std::make_tuple(B, H, W, C1);
+    auto it = m->block_plans.find(key);
+    if (it == m->block_plans.end()) {
+        Plan p;
+        const int rc = build_block_plan(m, &p, B, H, W, C1);
+        if (rc != OK) return rc;
+        it = m->block_plans.emplace(key, std::move(p)).first;
+    }
+    Plan* p = &it->second;
+    if (p->ws_bytes > m->d_ws_bytes) {
+        FLOWSE_HIP(hipDeviceSynchronize());
+        if (m->d_ws) FLOWSE_HIP(hipFree(m->d_ws));
+        m->d_ws = nullptr;
+        m->d_ws_bytes = 0;
+        FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_ws), p->ws_bytes));
+        m->d_ws_bytes = p->ws_bytes;
+    }
+    m->bcall.in1 = in1;
+    m->bcall.in2 = in2;
+    m->bcall.temb_act = temb_act;
+    m->bcall.out = out;
+    return run_plan(m, p, static_cast<hipStream_t>(stream));
 }
 
 int flowse_model_num_params(const flowse_model* m) { return m ? (int)m->params.size() : 0; }

@@ -66,6 +66,24 @@ int flowse_device_count(void);
 int flowse_model_create(const flowse_config* cfg, flowse_model** out);
 void flowse_model_destroy(flowse_model* m);
 
+/* ---- single-module handles (unit parity against the reference's modules) -------------------------------------
+ * A handle that holds ONE module of the network behind the same weight packer, launch planner and kernels the full
+ * model uses: FLOWSE_BLOCK_RESNET = ResnetBlockBigGANpp(in_ch, out_ch, up, down) (layerspp.py:212-274),
+ * FLOWSE_BLOCK_ATTN = AttnBlockpp(channels = in_ch = out_ch) (layerspp.py:62-91), FLOWSE_BLOCK_COMBINE =
+ * Combine(4 -> out_ch, 'sum') (layerspp.py:44-59).  The parameter table / canonical blob / flowse_model_load_weights
+ * calls work as for a model handle, with the reference's module-local keys under "all_modules.0." (GroupNorm_0.weight,
+ * Conv_0.weight, Dense_0.weight, NIN_0.W, ...).
+ * flowse_block_forward: NHWC float32 device tensors.  RESNET: out = block(cat[in1, in2], temb) with in1 [B,H,W,C1],
+ * in2 [B,H,W,in_ch-C1] or NULL (then C1 = in_ch); `temb_act` = SiLU(temb) [B][temb_dim] (the block applies Dense_0 to
+ * it, layerspp.py:262-263); out [B,H',W',out_ch] (H' = 2H / H/2 for up / down).  ATTN: out = block(in1).
+ * COMBINE: out = Conv_0(in1 [B,H,W,4]) + in2 [B,H,W,out_ch]. */
+#define FLOWSE_BLOCK_RESNET 0
+#define FLOWSE_BLOCK_ATTN 1
+#define FLOWSE_BLOCK_COMBINE 2
+int flowse_block_create(int kind, int in_ch, int out_ch, int up, int down, int temb_dim, flowse_model** out);
+int flowse_block_forward(flowse_model* m, const float* in1, int C1, const float* in2, const float* temb_act, float* out,
+                         int B, int H, int W, void* stream);
+
 /* Parameter table in the order of NCSNpp.parameters() / state_dict() (the order torch_ema's shadow_params
  * use, flowmse/model.py:81-103): output_layer.{weight,bias}, then all_modules.{i}.*.  `name` receives the
  * reference state_dict key; shape[0..ndim) the reference shape; `offset` the element offset of the tensor in

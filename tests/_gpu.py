@@ -171,3 +171,46 @@ def istft_decompress(spec, T, length, scale=1.0, factor=0.15, exponent=0.5):
                                          float(scale), stream()))
     torch.cuda.synchronize()
     return out.cpu()
+
+
+class Block:
+    """One reference module (ResnetBlockBigGANpp / AttnBlockpp / Combine) behind a single-module C-ABI handle."""
+    KINDS = {"resnet": 0, "attn": 1, "combine": 2}
+
+    def __init__(self, kind, in_ch, out_ch, up=False, down=False, temb_dim=64):
+        from flowmse_amd.backbones.structure import handle_param_table
+        self.h = C.c_void_p()
+        _lib.check(L.flowse_block_create(self.KINDS[kind], in_ch, out_ch, int(up), int(down), temb_dim, C.byref(self.h)))
+        self.names, self.shapes, self.offsets = handle_param_table(self.h)
+        self.kind, self.out_ch, self.up, self.down = kind, out_ch, up, down
+
+    def load(self, weights):
+        """weights: {module-local reference key (e.g. 'Conv_0.weight'): tensor}"""
+        blob = torch.zeros(int(L.flowse_model_blob_numel(self.h)))
+        for n, shp, off in zip(self.names, self.shapes, self.offsets):
+            w = weights[n[len("all_modules.0."):]].float()
+            assert list(w.shape) == shp, (n, tuple(w.shape), shp)
+            blob[off:off + w.numel()] = w.reshape(-1)
+        _lib.check(L.flowse_model_load_weights(self.h, C.c_void_p(blob.data_ptr()), blob.numel()))
+        return self
+
+    def __call__(self, x1, x2=None, temb=None):
+        """NCHW cpu tensors in, NCHW cpu out.  temb: raw time embedding [B, temb_dim] (SiLU applied here, as plumbing)."""
+        a1 = nhwc(x1)
+        a2 = nhwc(x2) if x2 is not None else None
+        B, H, W, C1 = a1.shape
+        ta = torch.nn.functional.silu(temb.float()).contiguous().cuda() if temb is not None else None
+        Ho, Wo = (2 * H, 2 * W) if self.up else (H // 2, W // 2) if self.down else (H, W)
+        out = torch.empty(B, Ho, Wo, self.out_ch, device="cuda")
+        _lib.check(L.flowse_block_forward(self.h, _lib.ptr(a1), C1, _lib.ptr(a2), _lib.ptr(ta), _lib.ptr(out), B, H, W,
+                                          stream()))
+        torch.cuda.synchronize()
+        return nchw(out)
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.flowse_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

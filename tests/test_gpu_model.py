@@ -386,6 +386,33 @@ def test_config5_shape(full):
     assert err < 5e-3
 
 
+@pytest.mark.timeout(1200)
+def test_config5_rk4_n25_sampler(full):
+    """BASELINE config 5 end to end: N = 25 fixed-step RK4 (97 network evaluations: 24 x 4 + the final Euler step),
+    batch 32 x T = 1024, fp16 operand mode.  No reference exists for this solver (the tableau itself is
+    pinned against the oracle at small size in test_fixed_step_rk_against_oracle_composition), so at full size the
+    checks are properties: finite, deterministic (bit-identical second run), batch independent (sample 5 alone equals
+    sample 5 in the batch to rounding), and a sane magnitude (the sampler moves x_T = y + 0.487 z towards |x| ~ |y|)."""
+    from flowmse_amd.sampling import get_white_box_solver
+    B, T, N = 32, 1024, 25
+    Y = torch.cat([C.c64(synth.synth_spectrogram(300 + i, 1, 256, T)) for i in range(B)]).cuda()
+    Z = torch.cat([C.c64(synth.synth_noise(300 + i, 1, 256, T)) for i in range(B)]).cuda()
+    full.dnn.set_precision("fp16")
+    try:
+        a, n = get_white_box_solver("rk4", full.ode, full, Y=Y, N=N, z=Z)()
+        a = a.clone()
+        b, _ = get_white_box_solver("rk4", full.ode, full, Y=Y, N=N, z=Z)()
+        one, _ = get_white_box_solver("rk4", full.ode, full, Y=Y[5:6].contiguous(), N=N, z=Z[5:6].contiguous())()
+    finally:
+        full.dnn.set_precision("fp32")
+    assert n == N and torch.isfinite(torch.view_as_real(a)).all()
+    assert torch.equal(a, b), "two runs of the N=25 RK4 sampler differ"
+    err = C.rel_l2(one.cpu(), a[5:6].cpu())
+    print("config 5: sample alone vs in batch rel-L2", err, " |x|/|y| =", float(a.abs().mean() / Y.abs().mean()))
+    assert err < 5e-3           # fp16 operands, different split plans at B = 1: rounding-level, not bitwise
+    assert 0.05 < float(a.abs().mean() / Y.abs().mean()) < 20.0
+
+
 def test_rejects_cpu_and_bad_shapes(tiny):
     xt, y, _ = C.tiny_inputs()
     with pytest.raises(RuntimeError):
