@@ -28,6 +28,79 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
         if (_e != hipSuccess) return ::flowse::hip_fail(_e, "kernel launch", __FILE__, __LINE__); \
     } while (0)
 
+// ------------------------------------------------------------------ activation storage types
+// Activations between kernels are NHWC tensors of float (default) or, in the 16-bit precision modes, bf16 / IEEE half
+// (BASELINE configs 3 / 5: half the HBM traffic of every HBM-bound kernel).  All arithmetic on them is fp32: a kernel
+// widens on load and rounds (to nearest even) once on store; GroupNorm statistics are taken over the ROUNDED values,
+// i.e. over exactly what the consumer will read.  The 4-channel tensors (input pack, input / output pyramids), all
+// statistics, time-embedding tables and split-K partial slabs stay fp32 in every mode.
+enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+struct bf16_t { unsigned short v; };
+struct f16_t { unsigned short v; };
+inline int dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+template <class ST> struct St;
+template <> struct St<float> {
+    static constexpr int dt = DT_F32;
+    static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+    static __device__ __forceinline__ float4 rnd4(float4 v) { return v; }      // value as it will be read back
+    static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+    static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+};
+template <> struct St<bf16_t> {
+    static constexpr int dt = DT_BF16;
+    static __device__ __forceinline__ float4 ld4(const bf16_t* p) {
+        const uint2 r = *reinterpret_cast<const uint2*>(p);
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                           __uint_as_float(r.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        const __bf16 x = (__bf16)a, y = (__bf16)b;                             // round to nearest even
+        return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+    }
+    static __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+    }
+    static __device__ __forceinline__ float4 rnd4(float4 v) {
+        const unsigned a = pack2(v.x, v.y), b = pack2(v.z, v.w);
+        return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16),
+                           __uint_as_float(b & 0xffff0000u));
+    }
+    static __device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((unsigned)p->v << 16); }
+    static __device__ __forceinline__ void st1(bf16_t* p, float v) {
+        const __bf16 x = (__bf16)v;
+        p->v = __builtin_bit_cast(unsigned short, x);
+    }
+};
+template <> struct St<f16_t> {
+    static constexpr int dt = DT_F16;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ float4 ld4(const f16_t* p) {
+        const h4 r = *reinterpret_cast<const h4*>(p);
+        return make_float4((float)r.x, (float)r.y, (float)r.z, (float)r.w);
+    }
+    static __device__ __forceinline__ void st4(f16_t* p, float4 v) {
+        h4 r = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<h4*>(p) = r;
+    }
+    static __device__ __forceinline__ float4 rnd4(float4 v) {
+        return make_float4((float)(_Float16)v.x, (float)(_Float16)v.y, (float)(_Float16)v.z, (float)(_Float16)v.w);
+    }
+    static __device__ __forceinline__ float ld1(const f16_t* p) { return (float)__builtin_bit_cast(_Float16, p->v); }
+    static __device__ __forceinline__ void st1(f16_t* p, float v) {
+        const _Float16 x = (_Float16)v;
+        p->v = __builtin_bit_cast(unsigned short, x);
+    }
+};
+// run `F.template operator()<ST>()` for the storage type tagged dt
+#define FLOWSE_DT_SWITCH(dt, ST, ...)                                          \
+    switch (dt) {                                                              \
+        case ::flowse::DT_F32: { using ST = float; __VA_ARGS__; } break;       \
+        case ::flowse::DT_BF16: { using ST = ::flowse::bf16_t; __VA_ARGS__; } break; \
+        default: { using ST = ::flowse::f16_t; __VA_ARGS__; } break;           \
+    }
+
 // GroupNorm parameters resolved per (sample, channel) by gn_finalize:
 //   y = (x - mean[b][c]) * scale[b][c] + beta[c],  scale = rstd * gamma
 struct GnParams {
@@ -83,6 +156,8 @@ __device__ __forceinline__ void chan_merge4(float& nA, float* acc8, float nB, co
 
 // ------------------------------------------------------------------ conv (implicit GEMM, MFMA fp32)
 struct ConvArgs {
+    // in1 / in2 hold elements of type in_dt, res / out of type out_dt (declared float*: the fp32 kernels use them as
+    // is, the 16-bit kernels reinterpret them); everything else is fp32
     const float* in1;   // [B][H][W][C1]
     const float* in2;   // [B][H][W][C2] or null: channel concat [in1, in2]
     int C1, C2;
@@ -120,7 +195,21 @@ struct ConvArgs {
     // F(2,3) (wino_f43 = 0, 12 transformed taps per channel pair) or F(4,3) (wino_f43 = 1, 18 taps)
     const float* wino = nullptr;
     int wino_f43 = 0;
+    // activation storage types (DT_*).  16-bit inputs are taken by the 16-bit matrix-core kernels (halo 3x3 with
+    // Cout % 128 == 0, flat 1x1 / small 3x3: `wq` = the [Cout][taps][Cin] weights in the matching 16-bit type, terms = 1)
+    // and by the 4-channel heads; 16-bit outputs by those plus the 4-channel input convs, the fp32 flat kernel
+    // (attention output projection) and the split-K reductions.
+    int in_dt = DT_F32, out_dt = DT_F32;
 };
+// K slices of the 16-bit flat kernel for a shape (its own policy: no Winograd alternative, two K steps per stage)
+int conv16_ksplit(int B, int H, int W, int Cin, int Cout, int taps);
+// true when a 3x3 conv with 16-bit operands runs the LDS-halo kernel (fused GroupNorm input possible, statistics of the
+// output fused, H*W/128 partial blocks); otherwise the flat 16-bit kernel (+ split-K) takes it
+bool conv16_uses_halo(int B, int H, int W, int C1, int C2, int Cout, int taps);
+// number of per-sample partial-statistics blocks the 16-bit conv path writes for this shape (0 = none)
+int conv16_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps);
+// elementwise storage conversion (n elements, n % 4 == 0)
+int launch_convert(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, hipStream_t s);
 // Winograd weight transforms along the kernel's vertical axis, packed [Cout][9][Cin] -> fragment order, on device
 int launch_wino_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s);
 int launch_f43_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s);
@@ -154,8 +243,9 @@ int launch_conv_cin4(const ConvArgs& a, hipStream_t s);
 // stats over (C/G channels) x H x W for a (possibly concatenated) NHWC tensor
 int gn_partial_blocks(int HW, int C);
 int gn_pixels_per_block(int HW, int nblk);      // ceil(HW / nblk): the block size every producer uses
-int launch_gn_stats(const float* in1, int C1, const float* in2, int C2, int B, int HW,
-                    float* partial /*[B][nblk][C][2]*/, int nblk, hipStream_t s);
+// dt / in_dt / out_dt: storage types of the activation tensors (DT_*); out_dt is DT_F32 or in_dt
+int launch_gn_stats(const void* in1, int C1, const void* in2, int C2, int B, int HW,
+                    float* partial /*[B][nblk][C][2]*/, int nblk, hipStream_t s, int dt = DT_F32);
 // statistics may come as two partial sets (channel concat of two tensors whose partials were produced
 // separately, e.g. by their conv epilogues): set 1 covers channels [0,C1), set 2 channels [C1, C1+C2)
 int launch_gn_finalize(const float* partial1, int nblk1, int C1, const float* partial2, int nblk2, int C2, int B,
@@ -163,20 +253,22 @@ int launch_gn_finalize(const float* partial1, int nblk1, int C1, const float* pa
                        float* scale /*[B][C]*/, hipStream_t s);
 
 // finalize + apply in one launch (small images: HW * C / G elements per block)
-int launch_gn_finalize_apply(const float* in1, const float* partial1, int nblk1, int C1, const float* in2,
+int launch_gn_finalize_apply(const void* in1, const float* partial1, int nblk1, int C1, const void* in2,
                              const float* partial2, int nblk2, int C2, int B, int HW, int G, const float* gamma,
-                             const float* beta, float eps, int silu, float* out, hipStream_t s);
-int launch_gn_apply(const float* in1, int C1, const float* in2, int C2, int B, int HW,
-                    GnParams gn, int silu, float* out, hipStream_t s);
+                             const float* beta, float eps, int silu, void* out, hipStream_t s, int in_dt = DT_F32,
+                             int out_dt = DT_F32);
+int launch_gn_apply(const void* in1, int C1, const void* in2, int C2, int B, int HW,
+                    GnParams gn, int silu, void* out, hipStream_t s, int in_dt = DT_F32, int out_dt = DT_F32);
 
 // ------------------------------------------------------------------ FIR resampling ([1,3,3,1] x [1,3,3,1] / 64)
 // down: out[B][H/2][W/2][C]; up: out[B][2H][2W][C] (gain 4).  Optional fused GN(+SiLU) on the input
 // (gn.mean == null -> raw), optional elementwise `add` tensor (same shape as out) summed into the result.
 // out2 (optional): the same resampling of the raw (un-normalised) input, written from the same read.
-int launch_fir_down(const float* in, int B, int H, int W, int C, GnParams gn, int silu, float* out,
-                    hipStream_t s, float* out2 = nullptr);
-int launch_fir_up(const float* in, int B, int H, int W, int C, GnParams gn, int silu, const float* add,
-                  float* out, hipStream_t s, float* out2 = nullptr);
+// dt: storage type of in / out / out2 / add (DT_*).
+int launch_fir_down(const void* in, int B, int H, int W, int C, GnParams gn, int silu, void* out,
+                    hipStream_t s, void* out2 = nullptr, int dt = DT_F32);
+int launch_fir_up(const void* in, int B, int H, int W, int C, GnParams gn, int silu, const void* add,
+                  void* out, hipStream_t s, void* out2 = nullptr, int dt = DT_F32);
 // generic NCHW upfirdn2d (drop-in for the reference's op/upfirdn2d ABI), kernel up to 8x8
 int launch_upfirdn2d_nchw(const float* in, const float* kernel, int planes, int in_h, int in_w, int kh,
                           int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,

@@ -79,9 +79,13 @@ static int allow_lds(size_t bytes) {
 // ---- shared epilogue.  The accumulators go through LDS (C/D layout of the 32x32 MFMA: col = lane & 31,
 // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) so that bias / per-sample bias / residual are read and the result
 // is written as coalesced float4 rows of the NHWC output.  Precondition: all waves are past their last LDS read.
-template <int WM, int WN, int TM, int TN, class Scatter>
+// OT = storage type of `res` and `out` (float, or bf16 / half in the 16-bit modes); the statistics are taken over the
+// values as rounded to OT, i.e. over what the consumer of `out` will read.
+template <int WM, int WN, int TM, int TN, class OT = float, class Scatter>
 __device__ __forceinline__ void conv_epilogue_with(const ConvArgs& a, float* smem, int m0, int n0, int M, int HW,
                                                    int split, int rowW, Scatter scatter) {
+    const OT* resp = reinterpret_cast<const OT*>(a.res);
+    OT* outp = reinterpret_cast<OT*>(a.out);
     // rowW == 0: tile row rr is flat pixel m0 + rr; rowW > 0: the tile is 8 x 16 pixels of an image with row
     // pitch rowW, m0 = its top-left pixel
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
@@ -104,7 +108,7 @@ __device__ __forceinline__ void conv_epilogue_with(const ConvArgs& a, float* sme
         for (int k = 0; k < NR; ++k) {
             const int rr = er0 + k * RPP;
             const int m = rowW ? m0 + (rr >> 4) * rowW + (rr & 15) : m0 + rr;
-            rres[k] = *reinterpret_cast<const float4*>(a.res + (m < M ? (int64_t)m * a.Cout : 0) + n);
+            rres[k] = St<OT>::ld4(resp + (m < M ? (int64_t)m * a.Cout : 0) + n);
         }
     }
     if (has_b2 && ncol) {
@@ -144,8 +148,8 @@ __device__ __forceinline__ void conv_epilogue_with(const ConvArgs& a, float* sme
             if (has_b2) { v.x += rb2[k].x; v.y += rb2[k].y; v.z += rb2[k].z; v.w += rb2[k].w; }
             if (has_res) { v.x += rres[k].x; v.y += rres[k].y; v.z += rres[k].z; v.w += rres[k].w; }
             v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
-            *reinterpret_cast<float4*>(a.out + (int64_t)m * a.Cout + n) = v;
-            st.add(v);
+            St<OT>::st4(outp + (int64_t)m * a.Cout + n, v);
+            st.add(St<OT>::rnd4(v));
         }
         if (a.stats) {
             // Fused GroupNorm statistics of the tile just written (launch guarantees: tile inside one sample, all
@@ -179,13 +183,13 @@ __device__ __forceinline__ void conv_epilogue_with(const ConvArgs& a, float* sme
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, class OT = float>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
                                               int M, int HW, int split, int rowW = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int li = lane & 31, kh = lane >> 5;
-    conv_epilogue_with<WM, WN, TM, TN>(a, smem, m0, n0, M, HW, split, rowW, [&](float* Cs, int CROW) {
+    conv_epilogue_with<WM, WN, TM, TN, OT>(a, smem, m0, n0, M, HW, split, rowW, [&](float* Cs, int CROW) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs a) 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0x80000000u;
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, class OT = float>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
     constexpr int A_LOADS = BM * 8 / NT, B_LOADS = BN * 8 / NT;
@@ -500,7 +504,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
         if (s + 1 < S) lstore(buf ^ 1);
         __syncthreads();
     }
-    conv_epilogue<WM, WN, TM, TN>(a, acc, smem, m0, n0, M, HW, split);
+    conv_epilogue<WM, WN, TM, TN, OT>(a, acc, smem, m0, n0, M, HW, split);
+}
+
+// One channel quad of an activation tensor through a buffer descriptor, widened to fp32 (bit patterns).  `voff` / `soff`
+// are BYTE offsets (element index * sizeof(ST)); out-of-range offsets return zeros for every type.
+template <class ST>
+__device__ __forceinline__ u32x4 buf_ld_quad(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (std::is_same<ST, float>::value) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    } else {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        u32x4 o;
+        if constexpr (std::is_same<ST, bf16_t>::value) {
+            o.x = t.x << 16; o.y = t.x & 0xffff0000u; o.z = t.y << 16; o.w = t.y & 0xffff0000u;
+        } else {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 a = __builtin_bit_cast(h2, t.x), b = __builtin_bit_cast(h2, t.y);
+            o.x = __float_as_uint((float)a.x); o.y = __float_as_uint((float)a.y);
+            o.z = __float_as_uint((float)b.x); o.w = __float_as_uint((float)b.y);
+        }
+        return o;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -736,20 +762,29 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     const size_t lds_epi = ((size_t)BM * (BN + 4) + 64 * WM * WN * 8) * sizeof(float);
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     if (const int rc = allow_lds<&conv_mfma_kernel<WM, WN, TM, TN>>(lds)) return rc;
-    if (const int rc = allow_lds<&conv_mfma_fast_kernel<WM, WN, TM, TN>>(lds)) return rc;
+    if (const int rc = allow_lds<&conv_mfma_fast_kernel<WM, WN, TM, TN, float>>(lds)) return rc;
+    if (const int rc = allow_lds<&conv_mfma_fast_kernel<WM, WN, TM, TN, bf16_t>>(lds)) return rc;
+    if (const int rc = allow_lds<&conv_mfma_fast_kernel<WM, WN, TM, TN, f16_t>>(lds)) return rc;
     // fast path: every K step is a full 32-channel chunk of one source; window / weight offsets fit 31 bits
     const bool fast = (a.C1 % KC) == 0 && (a.C2 % KC) == 0 &&
                       (int64_t)(BM + 2 * a.W + 2) * (a.C1 > a.C2 ? a.C1 : a.C2) * 4 < (1LL << 31) &&
                       (int64_t)a.Cout * a.taps * (a.C1 + a.C2) * 4 < (1LL << 31) && !g_force_generic;
-    if (fast)
-        hipLaunchKernelGGL((conv_mfma_fast_kernel<WM, WN, TM, TN>), dim3(grid, a.ksplit), dim3(64 * WM * WN), lds, s, a);
-    else
+    if (a.in_dt != DT_F32 || (a.out_dt != DT_F32 && !fast)) {
+        set_error("conv: the fp32 flat kernels take fp32 inputs (16-bit outputs only on the 32-channel-aligned path)");
+        return ERR_ARG;
+    }
+    if (fast) {
+        FLOWSE_DT_SWITCH(a.out_dt, OT, hipLaunchKernelGGL((conv_mfma_fast_kernel<WM, WN, TM, TN, OT>), dim3(grid, a.ksplit),
+                                                          dim3(64 * WM * WN), lds, s, a));
+    } else {
         hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN>), dim3(grid, a.ksplit), dim3(64 * WM * WN), lds, s, a);
+    }
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
 
 // out = (sum_s partial[s] + bias + bias2 + res) * scale, float4 streams; grid (ceil(HW * Cout/4 / 256), B)
+template <class OT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
     const unsigned Q = a.Cout >> 2;
     const unsigned HW = a.H * a.W;
@@ -774,11 +809,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     if (a.res) {
-        const float4 t = *reinterpret_cast<const float4*>(a.res + i4);
+        const float4 t = St<OT>::ld4(reinterpret_cast<const OT*>(a.res) + i4);
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
-    *reinterpret_cast<float4*>(a.out + i4) = v;
+    St<OT>::st4(reinterpret_cast<OT*>(a.out) + i4, v);
 }
 
 // Same reduction, organised like gn_stats (grid (HW / PB, B); a thread owns one channel quad and strides over the
@@ -788,6 +823,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
 // partials (every partial is later read by gn_finalize)
 static inline int sk_pixels_per_block(int HW) { return HW <= 8 ? HW : HW <= 1024 ? 8 : HW <= 4096 ? 32 : 64; }
 
+template <class OT>
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(ConvArgs a, int PB) {
     __shared__ float red[256 * 8];
     const int Q = a.Cout >> 2, PR = 256 / Q;
@@ -816,12 +852,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(ConvArgs a, in
             }
             v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
             if (a.res) {
-                const float4 t = *reinterpret_cast<const float4*>(a.res + i4);
+                const float4 t = St<OT>::ld4(reinterpret_cast<const OT*>(a.res) + i4);
                 v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
             }
             v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
-            *reinterpret_cast<float4*>(a.out + i4) = v;
-            st.add(v);
+            St<OT>::st4(reinterpret_cast<OT*>(a.out) + i4, v);
+            st.add(St<OT>::rnd4(v));
         }
     }
     float* mine = red + tid * 8;
@@ -1176,8 +1212,9 @@ int launch_wino_weights(const float* w_packed, int Cout, int Cin, float* out, hi
 // halo kernels) and the 4 x 9 x 32 weights sit in LDS; a lane's float4 fragment feeds four MFMAs.  HBM-read bound.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int GN>
+template <int GN, class ST = float>
 __global__ __launch_bounds__(256, 3) void conv3x3_head4_kernel(ConvArgs a) {
+    constexpr unsigned ES = sizeof(ST);                  // input element size (the 4-channel res / out stay fp32)
     constexpr int HPIX = 18 * 18;                        // halo pixels
     constexpr int H_LOADS = (HPIX * 8 + 255) / 256;      // 11 float4 per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1202,19 +1239,19 @@ __global__ __launch_bounds__(256, 3) void conv3x3_head4_kernel(ConvArgs a) {
         const int hr = row0 + 32 * q;
         const int hy = hr / 18, hx = hr - hy * 18;
         const bool in = hr < HPIX && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
-        hvo[q] = in ? (unsigned)((hy * W + hx) * Cin + col4 * 4) * 4u : OOB;
+        hvo[q] = in ? (unsigned)((hy * W + hx) * Cin + col4 * 4) * ES : OOB;
         hin |= in ? (1u << q) : 0u;
     }
     const int64_t wbase = (int64_t)m_tl - W - 1;
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.in1 + wbase * Cin), 0, (17 * W + 18) * Cin * 4, 0x00020000);
+        const_cast<ST*>(reinterpret_cast<const ST*>(a.in1) + wbase * Cin), 0, (17 * W + 18) * Cin * (int)ES, 0x00020000);
 
     u32x4 rh[H_LOADS];
     float4 g_mu, g_sc, g_be, rw0, rw1;
     auto gload = [&](int chunk) {
-        const unsigned soff = (unsigned)(chunk * KC) * 4u;
+        const unsigned soff = (unsigned)(chunk * KC) * ES;
 #pragma unroll
-        for (int q = 0; q < H_LOADS; ++q) rh[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc1, hvo[q], soff, 0);
+        for (int q = 0; q < H_LOADS; ++q) rh[q] = buf_ld_quad<ST>(rsrc1, hvo[q], soff);
         if (GN) {
             const int cg = chunk * KC + col4 * 4;
             g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
@@ -1288,12 +1325,16 @@ bool conv_supports_head4(int B, int H, int W, int C1, int C2, int Cout, int taps
 static int launch_head4(const ConvArgs& a, hipStream_t s) {
     const int grid = a.B * (a.H >> 4) * (a.W >> 4);
     const size_t lds = (size_t)(18 * 18 + 36) * LDS_ROW * sizeof(float);
+    if (a.out_dt != DT_F32) {
+        set_error("head4: the 4-channel output is fp32");
+        return ERR_ARG;
+    }
     if (a.gn.mean && a.gn_silu) {
-        hipLaunchKernelGGL(conv3x3_head4_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+        FLOWSE_DT_SWITCH(a.in_dt, ST, hipLaunchKernelGGL((conv3x3_head4_kernel<2, ST>), dim3(grid), dim3(256), lds, s, a));
     } else if (a.gn.mean) {
-        hipLaunchKernelGGL(conv3x3_head4_kernel<1>, dim3(grid), dim3(256), lds, s, a);
+        FLOWSE_DT_SWITCH(a.in_dt, ST, hipLaunchKernelGGL((conv3x3_head4_kernel<1, ST>), dim3(grid), dim3(256), lds, s, a));
     } else {
-        hipLaunchKernelGGL(conv3x3_head4_kernel<0>, dim3(grid), dim3(256), lds, s, a);
+        FLOWSE_DT_SWITCH(a.in_dt, ST, hipLaunchKernelGGL((conv3x3_head4_kernel<0, ST>), dim3(grid), dim3(256), lds, s, a));
     }
     FLOWSE_LAUNCH_CHECK();
     return OK;
@@ -1684,9 +1725,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // F16 = true: IEEE half operands (v_mfma_f32_32x32x16_f16, 11-bit mantissa; BASELINE config 5), TERMS must be 1.
-template <int TERMS, bool GN, bool F16 = false>
+// IT / OT: storage types of the input tensors and of res / out (float in the operand-only modes; the 16-bit type of
+// the operands in the 16-bit storage modes).
+template <int TERMS, bool GN, bool F16 = false, class IT = float, class OT = float>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
     static_assert(!F16 || TERMS == 1, "the half path has no split mode");
+    constexpr unsigned ES = sizeof(IT);
     constexpr int BN = 128, NT = 256;
     constexpr int PLANES = TERMS == 1 ? 1 : 2;
     constexpr int ROWB = PLANES * 64 + 16;               // LDS row stride in bytes
@@ -1720,8 +1764,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
         const int hr = row0 + 32 * q;
         const int hy = hr / 18, hx = hr - hy * 18;
         const bool in = hr < HROWS && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
-        hvo1[q] = in ? (unsigned)((hy * W + hx) * C1 + col4 * 4) * 4u : OOB;
-        hvo2[q] = in ? (unsigned)((hy * W + hx) * C2 + col4 * 4) * 4u : OOB;
+        hvo1[q] = in ? (unsigned)((hy * W + hx) * C1 + col4 * 4) * ES : OOB;
+        hvo2[q] = in ? (unsigned)((hy * W + hx) * C2 + col4 * 4) * ES : OOB;
         hin |= in ? (1u << q) : 0u;
     }
     const int bcol = tid % CPR, brow0 = tid / CPR;        // weight staging
@@ -1734,10 +1778,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
     }
     const int64_t wbase = (int64_t)m_tl - W - 1;
     const int wpix = 9 * W + 18;
+    const IT* in1p = reinterpret_cast<const IT*>(a.in1);
+    const IT* in2p = reinterpret_cast<const IT*>(a.in2);
     const __amdgpu_buffer_rsrc_t rsrc1 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1 + wbase * C1), 0, wpix * C1 * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<IT*>(in1p + wbase * C1), 0, wpix * C1 * (int)ES, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(C2 ? a.in2 + wbase * C2 : a.in1), 0, C2 ? wpix * C2 * 4 : 0, 0x00020000);
+        const_cast<IT*>(C2 ? in2p + wbase * C2 : in1p), 0, C2 ? wpix * C2 * (int)ES : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(a.wq), 0, a.Cout * 9 * nchunks * (PLANES * 64), 0x00020000);
 
@@ -1747,11 +1793,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
     auto gloadH = [&](int chunk) {
         const int c0 = chunk * KC;
         const bool second = c0 >= C1;
-        const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * 4u;
+        const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * ES;
 #pragma unroll
         for (int q = 0; q < H_LOADS; ++q)
-            rh[q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, hvo2[q], soff, 0)
-                           : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, hvo1[q], soff, 0);
+            rh[q] = second ? buf_ld_quad<IT>(rsrc2, hvo2[q], soff) : buf_ld_quad<IT>(rsrc1, hvo1[q], soff);
         if (GN) {
             const int cg = c0 + col4 * 4;
             g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
@@ -1915,7 +1960,242 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
         }
     }
 #undef FLOWSE_STEP16
-    conv_epilogue<2, 2, 2, 2>(a, acc, smem, m_tl, n0, M, HW, 0, W);
+    conv_epilogue<2, 2, 2, 2, OT>(a, acc, smem, m_tl, n0, M, HW, 0, W);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Flat-tiled 16-bit kernel for activations STORED as bf16 / half (BASELINE configs 3 / 5): the 1x1 shortcut
+// convolutions and every 3x3 the halo kernel does not take (W < 16, split-K shapes).  128 flat pixels x 128 output
+// channels per block, 4 waves x (2 x 2) tiles of v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulation.  A K step is one
+// (tap, 32-channel chunk) exactly as in the fp32 flat kernel -- same window descriptor, per-row tap masks and hardware
+// zero fill -- but TWO steps are staged per barrier (a 16-bit MFMA phase is 16x shorter than an fp32 one) and both
+// operands cross L2 -> LDS as 16-byte columns of eight channels.  Rows of 32 channels + 16 B pad (80 B) keep every
+// fragment read a conflict-free ds_read_b128.  Weights: the packed [Cout][taps][Cin] matrix in the same 16-bit type
+// (ConvArgs::wq).  gridDim.y = K slices (fp32 partial slabs + splitk_reduce, as for the fp32 kernel).
+template <bool F16, class OT>
+__global__ __launch_bounds__(256, 2) void conv_flat16_kernel(ConvArgs a) {
+    using T16 = typename std::conditional<F16, f16_t, bf16_t>::type;
+    constexpr int BM = 128, BN = 128, ROWB = 80, SLOT = 128 * ROWB;      // one (operand, step) tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* As = reinterpret_cast<char*>(smem);                              // [2 buffers][2 steps][BM][ROWB]
+    char* Bs = As + 4 * SLOT;                                              // [2 buffers][2 steps][BN][ROWB]
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int M = a.B * HW;
+    const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
+    const int taps = a.taps;
+    const int n_ntiles = (a.Cout + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
+    const int split = blockIdx.y;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int col = tid & 3, row0 = tid >> 2;                              // 16-byte column (8 channels), rows row0 + 64 q
+    unsigned avo1[2], avo2[2], tapmask[2], bvo[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = row0 + 64 * q;
+        const int m = m0 + r;
+        avo1[q] = (unsigned)(r * C1 + col * 8) * 2u;
+        avo2[q] = (unsigned)(r * C2 + col * 8) * 2u;
+        unsigned mask = 0;
+        if (m < M) {
+            const int rem = m % HW;
+            const int y = rem / W, x = rem - y * W;
+            if (taps == 9) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) mask |= 1u << t;
+                }
+            } else {
+                mask = 1u;
+            }
+        }
+        tapmask[q] = mask;
+        const int n = n0 + r;
+        bvo[q] = n < a.Cout ? (unsigned)(n * taps * Cin + col * 8) * 2u : OOB;
+    }
+    const int64_t wbase = (int64_t)m0 - W - 1;
+    const int wpix = BM + 2 * W + 2;
+    const T16* in1p = reinterpret_cast<const T16*>(a.in1);
+    const T16* in2p = reinterpret_cast<const T16*>(a.in2);
+    const __amdgpu_buffer_rsrc_t rsrc1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T16*>(in1p + wbase * C1), 0, wpix * C1 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T16*>(C2 ? in2p + wbase * C2 : in1p), 0, C2 ? wpix * C2 * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wq), 0, a.Cout * taps * Cin * 2, 0x00020000);
+
+    const int S_all = (Cin / KC) * taps;                                   // K steps
+    const int stages_all = (S_all + 1) >> 1;
+    const int per = (stages_all + a.ksplit - 1) / a.ksplit;
+    const int g_begin = split * per, g_end = min(stages_all, g_begin + per);
+
+    u32x4 ra[2][2], rb[2][2];                                              // [step of the stage][row group]
+    auto gload = [&](int stage) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int s = 2 * stage + j;
+            const bool live = s < S_all;                                   // odd step count: the last slot is all zeros
+            const int chunk = s / taps, tap = s - chunk * taps;
+            int shift = W + 1;
+            if (taps == 9) shift += (tap / 3 - 1) * W + (tap - (tap / 3) * 3 - 1);
+            const int c0 = chunk * KC;
+            const bool second = c0 >= C1;
+            const unsigned soff_a = (unsigned)(second ? shift * C2 + (c0 - C1) : shift * C1 + c0) * 2u;
+            const unsigned soff_b = (unsigned)(tap * Cin + c0) * 2u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool ok = live && ((tapmask[q] >> tap) & 1u);
+                const unsigned vo = ok ? (second ? avo2[q] : avo1[q]) : OOB;
+                ra[j][q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, vo, live ? soff_a : 0u, 0)
+                                  : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, vo, live ? soff_a : 0u, 0);
+                rb[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, live ? bvo[q] : OOB, live ? soff_b : 0u, 0);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int off = (buf * 2 + j) * SLOT + (row0 + 64 * q) * ROWB + col * 16;
+                *reinterpret_cast<u32x4*>(As + off) = ra[j][q];
+                *reinterpret_cast<u32x4*>(Bs + off) = rb[j][q];
+            }
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, kh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(g_begin);
+    lstore(0);
+    __syncthreads();
+    for (int g = g_begin; g < g_end; ++g) {
+        const int buf = (g - g_begin) & 1;
+        if (g + 1 < g_end) gload(g + 1);                                   // next stage in flight under the MFMAs
+        const char* Ab = As + buf * 2 * SLOT + (wm * 64 + li) * ROWB + kh * 16;
+        const char* Bb = Bs + buf * 2 * SLOT + (wn * 64 + li) * ROWB + kh * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+                bf16x8 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = *reinterpret_cast<const bf16x8*>(Ab + j * SLOT + i * 32 * ROWB + mh * 32);
+                    bf[i] = *reinterpret_cast<const bf16x8*>(Bb + j * SLOT + i * 32 * ROWB + mh * 32);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) {
+                        if (F16)
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]),
+                                                                               __builtin_bit_cast(f16x8, bf[jn]),
+                                                                               acc[i][jn], 0, 0, 0);
+                        else
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[jn], acc[i][jn], 0, 0, 0);
+                    }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < g_end) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    conv_epilogue<2, 2, 2, 2, OT>(a, acc, smem, m0, n0, M, HW, split);
+}
+
+// 16-bit path policies.  The halo kernel takes a 3x3 when its tiling applies and yields at least ~one block per two
+// CUs; everything else goes to the flat kernel, sliced along K (two-step stages, >= 2 stages per slice) until ~512
+// blocks exist.
+bool conv16_uses_halo(int B, int H, int W, int C1, int C2, int Cout, int taps) {
+    if (taps != 9 || (H & 7) || (W & 15) || (C1 % KC) || (C2 % KC) || (Cout % 128)) return false;
+    const int64_t cmax = C1 > C2 ? C1 : C2;
+    if ((int64_t)(9 * W + 18) * cmax * 4 >= (1LL << 31) || (int64_t)Cout * 9 * (C1 + C2) * 4 >= (1LL << 31)) return false;
+    return ((int64_t)B * H * W / 128) * (Cout / 128) >= 128;
+}
+
+int conv16_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
+    const int64_t M = (int64_t)B * H * W;
+    const int64_t tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
+    const int stages = ((Cin / KC) * taps + 1) / 2;
+    if (tiles >= 256 || stages < 4) return 1;
+    int64_t ks = (512 + tiles - 1) / tiles;
+    if (ks > stages / 2) ks = stages / 2;
+    if (ks < 1) ks = 1;
+    const int per = (int)((stages + ks - 1) / ks);
+    return (int)((stages + per - 1) / per);
+}
+
+int conv16_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps) {
+    const int HW = H * W;
+    if (Cout & 3) return 0;
+    if (taps == 9 && conv16_uses_halo(B, H, W, Cin, 0, Cout, taps)) return HW / 128;     // C1/C2 split is irrelevant here
+    if (conv16_ksplit(B, H, W, Cin, Cout, taps) != 1) {
+        const int PB = sk_pixels_per_block(HW);
+        return ((HW % PB) == 0 && Cout / 4 <= 256) ? HW / PB : 0;
+    }
+    return (HW % 128) == 0 ? HW / 128 : 0;
+}
+
+static int launch_flat16(const ConvArgs& a, hipStream_t s) {
+    if ((a.C1 % KC) || (a.C2 % KC) || !a.wq || a.terms != 1 || a.in_dt == DT_F32 || (a.wq_f16 ? DT_F16 : DT_BF16) != a.in_dt ||
+        (a.out_dt != DT_F32 && a.out_dt != a.in_dt) || a.gn.mean ||
+        (int64_t)(128 + 2 * a.W + 2) * (a.C1 > a.C2 ? a.C1 : a.C2) * 2 >= (1LL << 31) ||
+        (int64_t)a.Cout * a.taps * (a.C1 + a.C2) * 2 >= (1LL << 31)) {
+        set_error("flat16: unsupported configuration (C1=%d C2=%d in_dt=%d out_dt=%d)", a.C1, a.C2, a.in_dt, a.out_dt);
+        return ERR_ARG;
+    }
+    const int64_t M = (int64_t)a.B * a.H * a.W;
+    const int grid = (int)((M + 127) / 128) * ((a.Cout + 127) / 128);
+    const size_t lds = 8 * 128 * 80;                                       // > the epilogue's C tile + stats scratch
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+#define FLOWSE_L16(F16, OT)                                                                          \
+    {                                                                                                \
+        if (const int rc = allow_lds<&conv_flat16_kernel<F16, OT>>(lds)) return rc;                  \
+        hipLaunchKernelGGL((conv_flat16_kernel<F16, OT>), dim3(grid, ks), dim3(256), lds, s, a);     \
+    }
+    if (a.wq_f16) {
+        if (a.out_dt == DT_F32) FLOWSE_L16(true, float) else FLOWSE_L16(true, f16_t)
+    } else {
+        if (a.out_dt == DT_F32) FLOWSE_L16(false, float) else FLOWSE_L16(false, bf16_t)
+    }
+#undef FLOWSE_L16
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+// elementwise storage conversion (any pair of types), 4 elements per thread
+template <class SI, class SO>
+__global__ __launch_bounds__(256) void convert_kernel(const SI* __restrict__ src, SO* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        St<SO>::st4(dst + 4 * i, St<SI>::ld4(src + 4 * i));
+}
+
+int launch_convert(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, hipStream_t s) {
+    if (n & 3) {
+        set_error("convert: element count must be a multiple of 4");
+        return ERR_ARG;
+    }
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    FLOWSE_DT_SWITCH(src_dt, SI, FLOWSE_DT_SWITCH(dst_dt, SO, hipLaunchKernelGGL((convert_kernel<SI, SO>), dim3((unsigned)blocks),
+                                                                                 dim3(256), 0, s, static_cast<const SI*>(src),
+                                                                                 static_cast<SO*>(dst), n4)));
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
 }
 
 static unsigned short bf16_rne(float f) {
@@ -1982,12 +2262,30 @@ static int launch_halo_bf16(const ConvArgs& a, hipStream_t s) {
     const size_t lds_stage = (size_t)(180 + 2 * 128) * ROWB;
     const size_t lds_epi = ((size_t)128 * 132 + 256 * 8) * sizeof(float);
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    if (const int rc = allow_lds<&conv3x3_halo_bf16_kernel<TERMS, false, F16>>(lds)) return rc;
-    if (const int rc = allow_lds<&conv3x3_halo_bf16_kernel<TERMS, true, F16>>(lds)) return rc;
-    if (a.gn.mean)
-        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TERMS, true, F16>), dim3(grid), dim3(256), lds, s, a);
-    else
-        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TERMS, false, F16>), dim3(grid), dim3(256), lds, s, a);
+    if (a.in_dt != a.out_dt) {
+        set_error("halo16: input and output storage types must agree");
+        return ERR_ARG;
+    }
+    if (a.in_dt == DT_F32) {
+        if (const int rc = allow_lds<&conv3x3_halo_bf16_kernel<TERMS, false, F16>>(lds)) return rc;
+        if (const int rc = allow_lds<&conv3x3_halo_bf16_kernel<TERMS, true, F16>>(lds)) return rc;
+        if (a.gn.mean)
+            hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TERMS, true, F16>), dim3(grid), dim3(256), lds, s, a);
+        else
+            hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TERMS, false, F16>), dim3(grid), dim3(256), lds, s, a);
+    } else {
+        using T16 = typename std::conditional<F16, f16_t, bf16_t>::type;
+        if (TERMS != 1 || a.in_dt != St<T16>::dt) {
+            set_error("halo16: 16-bit storage needs the matching single-plane operand mode");
+            return ERR_ARG;
+        }
+        if (const int rc = allow_lds<&conv3x3_halo_bf16_kernel<1, false, F16, T16, T16>>(lds)) return rc;
+        if (const int rc = allow_lds<&conv3x3_halo_bf16_kernel<1, true, F16, T16, T16>>(lds)) return rc;
+        if (a.gn.mean)
+            hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<1, true, F16, T16, T16>), dim3(grid), dim3(256), lds, s, a);
+        else
+            hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<1, false, F16, T16, T16>), dim3(grid), dim3(256), lds, s, a);
+    }
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
@@ -2000,12 +2298,14 @@ int launch_splitk_reduce(const ConvArgs& a, hipStream_t s) {
             set_error("splitk_reduce: inconsistent fused-stats geometry");
             return ERR_ARG;
         }
-        hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(HW / PB, a.B), dim3(256), 0, s, a, PB);
+        FLOWSE_DT_SWITCH(a.out_dt, OT, hipLaunchKernelGGL(splitk_reduce_stats_kernel<OT>, dim3(HW / PB, a.B), dim3(256), 0, s,
+                                                          a, PB));
         FLOWSE_LAUNCH_CHECK();
         return OK;
     }
     const unsigned per_sample = (unsigned)HW * (a.Cout / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((per_sample + 255) / 256, a.B), dim3(256), 0, s, a);
+    FLOWSE_DT_SWITCH(a.out_dt, OT, hipLaunchKernelGGL(splitk_reduce_kernel<OT>, dim3((per_sample + 255) / 256, a.B),
+                                                      dim3(256), 0, s, a));
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
@@ -2019,6 +2319,22 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
     if ((int64_t)a.B * a.H * a.W >= (1LL << 31) / 4) {
         set_error("conv: too many pixels for 32-bit pixel indices");
         return ERR_SHAPE;
+    }
+    if (a.in_dt != DT_F32) {                          // activations stored as bf16 / half
+        if (a.ksplit <= 1 && !a.partial && !a.bias2 && !a.stats && a.out_dt == DT_F32 &&
+            conv_supports_head4(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))
+            return launch_head4(a, s);
+        if (a.ksplit <= 1 && a.out_dt == a.in_dt && conv16_uses_halo(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
+            if (a.wq_f16) return launch_halo_bf16<1, true>(a, s);
+            return launch_halo_bf16<1>(a, s);
+        }
+        if (a.ksplit > 1 && !a.partial) {
+            set_error("conv: split-K needs a partial buffer");
+            return ERR_ARG;
+        }
+        const int rc = launch_flat16(a, s);
+        if (rc != OK || a.ksplit <= 1 || !with_reduce) return rc;
+        return launch_splitk_reduce(a, s);
     }
     if (a.ksplit <= 1 && !a.partial && !a.bias2 && !a.stats && conv_supports_head4(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))
         return launch_head4(a, s);
@@ -2064,7 +2380,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
 // Direct VALU convolution for 4 input channels: the input layer conv3x3 4->nf (ncsnpp.py:159,285) and the
 // Combine conv1x1 4->C (layerspp.py:44-59).  K = 36 / 4 is too short for the matrix cores; these layers are
 // bound by the HBM write of the output.  One thread = one pixel x 4 output channels; weights live in LDS.
-template <int TAPS>
+template <int TAPS, class OT>
 __global__ __launch_bounds__(256) void conv_cin4_kernel(ConvArgs a, int Q) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [Cout][TAPS][4]
     const int tid = threadIdx.x;
@@ -2108,11 +2424,11 @@ __global__ __launch_bounds__(256) void conv_cin4_kernel(ConvArgs a, int Q) {
     }
     const int64_t off = m * a.Cout + cq * 4;
     if (a.res) {
-        const float4 r = *reinterpret_cast<const float4*>(a.res + off);
+        const float4 r = St<OT>::ld4(reinterpret_cast<const OT*>(a.res) + off);
         o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
     }
-    *reinterpret_cast<float4*>(a.out + off) =
-        make_float4(o[0] * a.scale, o[1] * a.scale, o[2] * a.scale, o[3] * a.scale);
+    St<OT>::st4(reinterpret_cast<OT*>(a.out) + off,
+                make_float4(o[0] * a.scale, o[1] * a.scale, o[2] * a.scale, o[3] * a.scale));
 }
 
 // Matrix-core form of the 4 -> 128 input convolution for full-size images: K = 9 taps x 4 channels = 36 (+4 zero),
@@ -2120,6 +2436,7 @@ __global__ __launch_bounds__(256) void conv_cin4_kernel(ConvArgs a, int Q) {
 // read straight from global memory; the whole 128 x 40 weight matrix sits in registers.  Block = 128 flat pixels x 128
 // channels, wave = 32 pixels x 128 channels (4 accumulator tiles); output-write bound.  Shares the standard epilogue,
 // i.e. also emits the GroupNorm partial statistics of its output.
+template <class OT>
 __global__ __launch_bounds__(256, 2) void conv3x3_cin4_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -2159,7 +2476,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_cin4_mfma_kernel(ConvArgs a) {
             acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, w4.w, acc[0][j], 0, 0, 0);
         }
     }
-    conv_epilogue<4, 1, 1, 4>(a, acc, smem, m0, 0, M, HW, 0);
+    conv_epilogue<4, 1, 1, 4, OT>(a, acc, smem, m0, 0, M, HW, 0);
 }
 
 bool conv_cin4_uses_mfma(int B, int H, int W, int Cout, int taps) {
@@ -2171,9 +2488,11 @@ int launch_conv_cin4(const ConvArgs& a, hipStream_t s) {
     const int Q = a.Cout / 4;
     if (a.C1 == 4 && a.C2 == 0 && a.ksplit <= 1 && !a.gn.mean && conv_cin4_uses_mfma(a.B, a.H, a.W, a.Cout, a.taps)) {
         const size_t lds = ((size_t)128 * (128 + 4) + 256 * 8) * sizeof(float);
-        if (const int rc = allow_lds<&conv3x3_cin4_mfma_kernel>(lds)) return rc;
+        if (const int rc = allow_lds<&conv3x3_cin4_mfma_kernel<float>>(lds)) return rc;
+        if (const int rc = allow_lds<&conv3x3_cin4_mfma_kernel<bf16_t>>(lds)) return rc;
+        if (const int rc = allow_lds<&conv3x3_cin4_mfma_kernel<f16_t>>(lds)) return rc;
         const int grid = (int)((int64_t)a.B * a.H * a.W / 128);
-        hipLaunchKernelGGL(conv3x3_cin4_mfma_kernel, dim3(grid), dim3(256), lds, s, a);
+        FLOWSE_DT_SWITCH(a.out_dt, OT, hipLaunchKernelGGL(conv3x3_cin4_mfma_kernel<OT>, dim3(grid), dim3(256), lds, s, a));
         FLOWSE_LAUNCH_CHECK();
         return OK;
     }
@@ -2185,10 +2504,11 @@ int launch_conv_cin4(const ConvArgs& a, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int grid = (int)((M + ppb - 1) / ppb);
     const size_t lds = (size_t)a.Cout * a.taps * 16;
-    if (a.taps == 9)
-        hipLaunchKernelGGL(conv_cin4_kernel<9>, dim3(grid), dim3(256), lds, s, a, Q);
-    else
-        hipLaunchKernelGGL(conv_cin4_kernel<1>, dim3(grid), dim3(256), lds, s, a, Q);
+    if (a.taps == 9) {
+        FLOWSE_DT_SWITCH(a.out_dt, OT, hipLaunchKernelGGL((conv_cin4_kernel<9, OT>), dim3(grid), dim3(256), lds, s, a, Q));
+    } else {
+        FLOWSE_DT_SWITCH(a.out_dt, OT, hipLaunchKernelGGL((conv_cin4_kernel<1, OT>), dim3(grid), dim3(256), lds, s, a, Q));
+    }
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }

@@ -8,8 +8,7 @@
 //        even o = 2a:   (1 * in[a-1] + 3 * in[a]) / 4        odd o = 2a+1:  (3 * in[a] + 1 * in[a+1]) / 4
 //        per axis (the polyphase form of the same 4-tap filter); samples outside the image are zero.
 //
-// Depth-wise and identical for every channel, so in NHWC each thread owns one output pixel x one channel quad
-// and every access is a coalesced float4.  Optional fusions: GroupNorm(+SiLU) applied to the input samples on
+// Depth-wise and identical for every channel: NHWC, channel quads per thread, 128-byte runs per pixel.  Optional fusions: GroupNorm(+SiLU) applied to the input samples on
 // load (ResnetBlockBigGANpp resamples act(GroupNorm_0(x)), layerspp.py:246-259) and an elementwise `add`
 // (output pyramid: pyramid = upsample(pyramid) + pyramid_h, ncsnpp.py:354-359).
 #include "common.h"
@@ -46,106 +45,136 @@ __device__ __forceinline__ GnQuad gn_quad(const GnParams& gn, int silu, int b, i
     return g;
 }
 
-// grid: (ceil(OW * C/4 / 256), OH, B); one thread = one output pixel x one channel quad (32-bit index math only)
-// out2 (optional): the same resampling of the RAW input (the ResnetBlock's shortcut branch resamples x while the
-// main branch resamples act(GroupNorm(x)), layerspp.py:251-259): both from one read of the input
-__global__ __launch_bounds__(256) void fir_down_kernel(const float* __restrict__ in, int H, int W, int C, GnParams gn,
-                                                       int silu, float* __restrict__ out, float* __restrict__ out2) {
-    const unsigned Q = C >> 2, OW = W >> 1, OH = H >> 1;
-    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
-    if (idx >= OW * Q) return;
-    const unsigned ox = idx / Q, cq = idx - ox * Q;
-    const int oy = blockIdx.y, b = blockIdx.z;
-    const int c = cq * 4;
-    const float k1[4] = {1.f, 3.f, 3.f, 1.f};
-    const GnQuad g = gn_quad(gn, silu, b, C, c);
-    const float* base = in + (int64_t)b * H * W * C + c;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
-#pragma unroll
-    for (int ty = 0; ty < 4; ++ty) {
-        const int y = 2 * oy - 1 + ty;
-        if ((unsigned)y >= (unsigned)H) continue;
-        float4 row = make_float4(0.f, 0.f, 0.f, 0.f), row2 = row;
-#pragma unroll
-        for (int tx = 0; tx < 4; ++tx) {
-            const int x = 2 * (int)ox - 1 + tx;
-            if ((unsigned)x >= (unsigned)W) continue;
-            const float4 r = *reinterpret_cast<const float4*>(base + ((int64_t)y * W + x) * C);
-            const float4 v = apply_tx(r, g);
-            row.x = fmaf(k1[tx], v.x, row.x); row.y = fmaf(k1[tx], v.y, row.y);
-            row.z = fmaf(k1[tx], v.z, row.z); row.w = fmaf(k1[tx], v.w, row.w);
-            if (out2) {
-                row2.x = fmaf(k1[tx], r.x, row2.x); row2.y = fmaf(k1[tx], r.y, row2.y);
-                row2.z = fmaf(k1[tx], r.z, row2.z); row2.w = fmaf(k1[tx], r.w, row2.w);
-            }
+// Both kernels work on LDS tiles: a block stages the input window of its output tile ONCE -- with the fused
+// GroupNorm(+SiLU) applied on the way in, so every input element is normalised once per block instead of once per tap
+// (4x per element for the down filter, 16x for the up filter in a thread-per-output formulation) -- and every output
+// is then a handful of conflict-free ds_read_b128.  A block covers CC = 32 channels (8 quads): thread = (pixel lane,
+// channel quad), global accesses are 128-byte runs per pixel.  Samples outside the image are zero (also after the
+// fused activation).  ST = storage type of `in` / `out` / `out2` / `add` (float, bf16, half; arithmetic is fp32).
+// out2 (optional): the same resampling of the RAW input (the ResnetBlock's shortcut branch resamples x while the main
+// branch resamples act(GroupNorm(x)), layerspp.py:251-259): both from one read of the input.
+constexpr int FIR_CC = 32;                 // channels per block
+
+// down: output tile 4 x 8, input window 10 x 18.  grid (tiles_x * tiles_y, ceil(C / 32), B)
+template <class ST>
+__global__ __launch_bounds__(256) void fir_down_kernel(const ST* __restrict__ in, int H, int W, int C, GnParams gn,
+                                                       int silu, ST* __restrict__ out, ST* __restrict__ out2,
+                                                       int tiles_x) {
+    constexpr int TY = 4, TX = 8, IY = 2 * TY + 2, IX = 2 * TX + 2, NPX = IY * IX;
+    __shared__ __attribute__((aligned(16))) float tile[2][NPX][FIR_CC];      // [0] transformed, [1] raw (out2 only)
+    const int OH = H >> 1, OW = W >> 1;
+    const int t = threadIdx.x, q = t & 7, pl = t >> 3;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int b = blockIdx.z, c = blockIdx.y * FIR_CC + q * 4;
+    const bool cok = c < C;
+    const int oy0 = ty * TY, ox0 = tx * TX;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+    const GnQuad g = cok ? gn_quad(gn, silu, b, C, c) : GnQuad{};
+    const ST* base = in + (int64_t)b * H * W * C + (cok ? c : 0);
+    for (int p = pl; p < NPX; p += 32) {
+        const int py = p / IX, px = p - py * IX;
+        const int y = iy0 + py, x = ix0 + px;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f), v = r;
+        if (cok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            r = St<ST>::ld4(base + ((int64_t)y * W + x) * C);
+            v = apply_tx(r, g);
         }
-        acc.x = fmaf(k1[ty], row.x, acc.x); acc.y = fmaf(k1[ty], row.y, acc.y);
-        acc.z = fmaf(k1[ty], row.z, acc.z); acc.w = fmaf(k1[ty], row.w, acc.w);
-        if (out2) {
-            acc2.x = fmaf(k1[ty], row2.x, acc2.x); acc2.y = fmaf(k1[ty], row2.y, acc2.y);
-            acc2.z = fmaf(k1[ty], row2.z, acc2.z); acc2.w = fmaf(k1[ty], row2.w, acc2.w);
-        }
+        *reinterpret_cast<float4*>(&tile[0][p][q * 4]) = v;
+        if (out2) *reinterpret_cast<float4*>(&tile[1][p][q * 4]) = r;
     }
+    __syncthreads();
+    const int oyl = pl >> 3, oxl = pl & 7;                                   // 32 pixel lanes = the 4 x 8 outputs
+    const int oy = oy0 + oyl, ox = ox0 + oxl;
+    if (!cok || oy >= OH || ox >= OW) return;
+    const float k1[4] = {1.f, 3.f, 3.f, 1.f};
     const float s = 1.f / 64.f;
     const int64_t off = (((int64_t)b * OH + oy) * OW + ox) * C + c;
-    *reinterpret_cast<float4*>(out + off) = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
-    if (out2) *reinterpret_cast<float4*>(out2 + off) = make_float4(acc2.x * s, acc2.y * s, acc2.z * s, acc2.w * s);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (which == 1 && !out2) break;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int fy = 0; fy < 4; ++fy) {
+            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int fx = 0; fx < 4; ++fx) {
+                const float4 v = *reinterpret_cast<const float4*>(&tile[which][(2 * oyl + fy) * IX + 2 * oxl + fx][q * 4]);
+                row.x = fmaf(k1[fx], v.x, row.x); row.y = fmaf(k1[fx], v.y, row.y);
+                row.z = fmaf(k1[fx], v.z, row.z); row.w = fmaf(k1[fx], v.w, row.w);
+            }
+            acc.x = fmaf(k1[fy], row.x, acc.x); acc.y = fmaf(k1[fy], row.y, acc.y);
+            acc.z = fmaf(k1[fy], row.z, acc.z); acc.w = fmaf(k1[fy], row.w, acc.w);
+        }
+        St<ST>::st4((which ? out2 : out) + off, make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s));
+    }
 }
 
-// grid: (ceil(2W * C/4 / 256), 2H, B)
-__global__ __launch_bounds__(256) void fir_up_kernel(const float* __restrict__ in, int H, int W, int C, GnParams gn,
-                                                     int silu, const float* __restrict__ add, float* __restrict__ out,
-                                                     float* __restrict__ out2) {
-    const unsigned Q = C >> 2, OW = W * 2, OH = H * 2;
-    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
-    if (idx >= OW * Q) return;
-    const unsigned ox = idx / Q, cq = idx - ox * Q;
-    const int oy = blockIdx.y, b = blockIdx.z;
-    const int c = cq * 4;
-    const GnQuad g = gn_quad(gn, silu, b, C, c);
-    const float* base = in + (int64_t)b * H * W * C + c;
-    // per axis: two taps (position, weight); even: (a-1, 1), (a, 3); odd: (a, 3), (a+1, 1)
-    const int ay = oy >> 1, ax = ox >> 1;
-    const int y0 = (oy & 1) ? ay : ay - 1, x0 = (ox & 1) ? ax : ax - 1;
-    const float wy0 = (oy & 1) ? 3.f : 1.f, wy1 = (oy & 1) ? 1.f : 3.f;
-    const float wx0 = (ox & 1) ? 3.f : 1.f, wx1 = (ox & 1) ? 1.f : 3.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
+// up: input tile 8 x 8 (+1 halo) -> output tile 16 x 16.  grid (tiles_x * tiles_y, ceil(C / 32), B)
+template <class ST>
+__global__ __launch_bounds__(256) void fir_up_kernel(const ST* __restrict__ in, int H, int W, int C, GnParams gn,
+                                                     int silu, const ST* __restrict__ add, ST* __restrict__ out,
+                                                     ST* __restrict__ out2, int tiles_x) {
+    constexpr int TY = 8, TX = 8, IY = TY + 2, IX = TX + 2, NPX = IY * IX;
+    __shared__ __attribute__((aligned(16))) float tile[2][NPX][FIR_CC];
+    const int OH = 2 * H, OW = 2 * W;
+    const int t = threadIdx.x, q = t & 7, pl = t >> 3;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int b = blockIdx.z, c = blockIdx.y * FIR_CC + q * 4;
+    const bool cok = c < C;
+    const int iy0 = ty * TY - 1, ix0 = tx * TX - 1;
+    const GnQuad g = cok ? gn_quad(gn, silu, b, C, c) : GnQuad{};
+    const ST* base = in + (int64_t)b * H * W * C + (cok ? c : 0);
+    for (int p = pl; p < NPX; p += 32) {
+        const int py = p / IX, px = p - py * IX;
+        const int y = iy0 + py, x = ix0 + px;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f), v = r;
+        if (cok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            r = St<ST>::ld4(base + ((int64_t)y * W + x) * C);
+            v = apply_tx(r, g);
+        }
+        *reinterpret_cast<float4*>(&tile[0][p][q * 4]) = v;
+        if (out2) *reinterpret_cast<float4*>(&tile[1][p][q * 4]) = r;
+    }
+    __syncthreads();
+    if (!cok) return;
+    // per axis: two taps (position, weight); even o = 2a: (a-1, 1), (a, 3); odd o = 2a+1: (a, 3), (a+1, 1)
+    const float sc = 1.f / 16.f;
+    const int oxl = pl & 15;                                                 // 16 columns x 2 rows per pass
+    const int ox = 2 * tx * TX + oxl;
+    if (ox >= OW) return;
+    const int axl = oxl >> 1;
+    const int lx0 = (oxl & 1) ? axl + 1 : axl;                               // local column of the first tap (+1 halo)
+    const float wx0 = (oxl & 1) ? 3.f : 1.f, wx1 = (oxl & 1) ? 1.f : 3.f;
+#pragma unroll 2
+    for (int pass = 0; pass < 8; ++pass) {
+        const int oyl = pass * 2 + (pl >> 4);
+        const int oy = 2 * ty * TY + oyl;
+        if (oy >= OH) break;
+        const int ayl = oyl >> 1;
+        const int ly0 = (oyl & 1) ? ayl + 1 : ayl;
+        const float wy0 = (oyl & 1) ? 3.f : 1.f, wy1 = (oyl & 1) ? 1.f : 3.f;
+        const int64_t off = (((int64_t)b * OH + oy) * OW + ox) * C + c;
 #pragma unroll
-    for (int ty = 0; ty < 2; ++ty) {
-        const int y = y0 + ty;
-        if ((unsigned)y >= (unsigned)H) continue;
-        const float wy = ty ? wy1 : wy0;
-        float4 row = make_float4(0.f, 0.f, 0.f, 0.f), row2 = row;
-#pragma unroll
-        for (int tx = 0; tx < 2; ++tx) {
-            const int x = x0 + tx;
-            if ((unsigned)x >= (unsigned)W) continue;
-            const float wx = tx ? wx1 : wx0;
-            const float4 r = *reinterpret_cast<const float4*>(base + ((int64_t)y * W + x) * C);
-            const float4 v = apply_tx(r, g);
-            row.x = fmaf(wx, v.x, row.x); row.y = fmaf(wx, v.y, row.y);
-            row.z = fmaf(wx, v.z, row.z); row.w = fmaf(wx, v.w, row.w);
-            if (out2) {
-                row2.x = fmaf(wx, r.x, row2.x); row2.y = fmaf(wx, r.y, row2.y);
-                row2.z = fmaf(wx, r.z, row2.z); row2.w = fmaf(wx, r.w, row2.w);
+        for (int which = 0; which < 2; ++which) {
+            if (which == 1 && !out2) break;
+            const float4 v00 = *reinterpret_cast<const float4*>(&tile[which][ly0 * IX + lx0][q * 4]);
+            const float4 v01 = *reinterpret_cast<const float4*>(&tile[which][ly0 * IX + lx0 + 1][q * 4]);
+            const float4 v10 = *reinterpret_cast<const float4*>(&tile[which][(ly0 + 1) * IX + lx0][q * 4]);
+            const float4 v11 = *reinterpret_cast<const float4*>(&tile[which][(ly0 + 1) * IX + lx0 + 1][q * 4]);
+            float4 r0, r1, o;
+            r0.x = fmaf(wx1, v01.x, fmaf(wx0, v00.x, 0.f)); r0.y = fmaf(wx1, v01.y, fmaf(wx0, v00.y, 0.f));
+            r0.z = fmaf(wx1, v01.z, fmaf(wx0, v00.z, 0.f)); r0.w = fmaf(wx1, v01.w, fmaf(wx0, v00.w, 0.f));
+            r1.x = fmaf(wx1, v11.x, fmaf(wx0, v10.x, 0.f)); r1.y = fmaf(wx1, v11.y, fmaf(wx0, v10.y, 0.f));
+            r1.z = fmaf(wx1, v11.z, fmaf(wx0, v10.z, 0.f)); r1.w = fmaf(wx1, v11.w, fmaf(wx0, v10.w, 0.f));
+            o.x = fmaf(wy1, r1.x, fmaf(wy0, r0.x, 0.f)) * sc; o.y = fmaf(wy1, r1.y, fmaf(wy0, r0.y, 0.f)) * sc;
+            o.z = fmaf(wy1, r1.z, fmaf(wy0, r0.z, 0.f)) * sc; o.w = fmaf(wy1, r1.w, fmaf(wy0, r0.w, 0.f)) * sc;
+            if (which == 0 && add) {
+                const float4 r = St<ST>::ld4(add + off);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
-        }
-        acc.x = fmaf(wy, row.x, acc.x); acc.y = fmaf(wy, row.y, acc.y);
-        acc.z = fmaf(wy, row.z, acc.z); acc.w = fmaf(wy, row.w, acc.w);
-        if (out2) {
-            acc2.x = fmaf(wy, row2.x, acc2.x); acc2.y = fmaf(wy, row2.y, acc2.y);
-            acc2.z = fmaf(wy, row2.z, acc2.z); acc2.w = fmaf(wy, row2.w, acc2.w);
+            St<ST>::st4((which ? out2 : out) + off, o);
         }
     }
-    const float s = 1.f / 16.f;
-    float4 o = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
-    const int64_t off = (((int64_t)b * OH + oy) * OW + ox) * C + c;
-    if (add) {
-        const float4 r = *reinterpret_cast<const float4*>(add + off);
-        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-    }
-    *reinterpret_cast<float4*>(out + off) = o;
-    if (out2) *reinterpret_cast<float4*>(out2 + off) = make_float4(acc2.x * s, acc2.y * s, acc2.z * s, acc2.w * s);
 }
 
 static int grid_for(int64_t total) {
@@ -155,28 +184,31 @@ static int grid_for(int64_t total) {
     return (int)blocks;
 }
 
-int launch_fir_down(const float* in, int B, int H, int W, int C, GnParams gn, int silu, float* out, hipStream_t s,
-                    float* out2) {
-    if ((C & 3) || (H & 1) || (W & 1) || H / 2 > 65535 || B > 65535) {
+int launch_fir_down(const void* in, int B, int H, int W, int C, GnParams gn, int silu, void* out, hipStream_t s,
+                    void* out2, int dt) {
+    const int tiles_x = (W / 2 + 7) / 8, tiles_y = (H / 2 + 3) / 4, cg = (C + FIR_CC - 1) / FIR_CC;
+    if ((C & 3) || (H & 1) || (W & 1) || cg > 65535 || B > 65535) {
         set_error("fir_down: unsupported shape B=%d H=%d W=%d C=%d", B, H, W, C);
         return ERR_SHAPE;
     }
-    const unsigned per_row = (unsigned)(W / 2) * (C / 4);
-    hipLaunchKernelGGL(fir_down_kernel, dim3((per_row + 255) / 256, H / 2, B), dim3(256), 0, s, in, H, W, C, gn, silu,
-                       out, out2);
+    FLOWSE_DT_SWITCH(dt, ST, hipLaunchKernelGGL(fir_down_kernel<ST>, dim3(tiles_x * tiles_y, cg, B), dim3(256), 0, s,
+                                                static_cast<const ST*>(in), H, W, C, gn, silu, static_cast<ST*>(out),
+                                                static_cast<ST*>(out2), tiles_x));
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
 
-int launch_fir_up(const float* in, int B, int H, int W, int C, GnParams gn, int silu, const float* add, float* out,
-                  hipStream_t s, float* out2) {
-    if ((C & 3) || H * 2 > 65535 || B > 65535) {
+int launch_fir_up(const void* in, int B, int H, int W, int C, GnParams gn, int silu, const void* add, void* out,
+                  hipStream_t s, void* out2, int dt) {
+    const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8, cg = (C + FIR_CC - 1) / FIR_CC;
+    if ((C & 3) || cg > 65535 || B > 65535) {
         set_error("fir_up: unsupported shape B=%d H=%d C=%d", B, H, C);
         return ERR_SHAPE;
     }
-    const unsigned per_row = (unsigned)(W * 2) * (C / 4);
-    hipLaunchKernelGGL(fir_up_kernel, dim3((per_row + 255) / 256, H * 2, B), dim3(256), 0, s, in, H, W, C, gn, silu, add,
-                       out, out2);
+    FLOWSE_DT_SWITCH(dt, ST, hipLaunchKernelGGL(fir_up_kernel<ST>, dim3(tiles_x * tiles_y, cg, B), dim3(256), 0, s,
+                                                static_cast<const ST*>(in), H, W, C, gn, silu,
+                                                static_cast<const ST*>(add), static_cast<ST*>(out),
+                                                static_cast<ST*>(out2), tiles_x));
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }

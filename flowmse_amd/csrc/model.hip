@@ -62,7 +62,8 @@ struct Tn {
     int B = 0, H = 0, W = 0, C = 0;
     size_t st_off = 0;      // fused GroupNorm partials written by the producing conv (st_nblk blocks per sample)
     int st_nblk = 0;
-    size_t bytes() const { return (size_t)B * H * W * C * sizeof(float); }
+    int dt = DT_F32;        // storage type of the elements (DT_*)
+    size_t bytes() const { return (size_t)B * H * W * C * dt_size(dt); }
     bool valid() const { return B > 0; }
 };
 
@@ -154,6 +155,11 @@ struct flowse_model {
     int precision = 0;                     // 0 fp32 (exact), 1 bf16x3 split (fp32-class), 2 bf16, 3 fp16 operands
     uint16_t* d_wq = nullptr;              // bf16 planes of the 3x3 ResBlock convs (precision != 0)
     int64_t d_wq_numel = 0;
+    // 16-bit STORAGE modes (precision 2 / 3 on networks whose wide channel counts are multiples of 32): activations
+    // between kernels are bf16 / half; d_w16 is an elementwise 16-bit copy of the packed weight blob d_w (same offsets)
+    int act_dt = DT_F32;
+    uint16_t* d_w16 = nullptr;
+    int64_t d_w16_numel = 0;
     float* d_wino = nullptr;               // F(2,3) Winograd weights of the 3x3 convs the halo kernel can take
     int64_t d_wino_numel = 0;
     std::map<int64_t, int64_t> wino_of;    // packed weight offset (d_w) -> offset in d_wino
@@ -184,6 +190,7 @@ struct flowse_model {
 
     float* W(int64_t off) const { return d_w + off; }
     float* A(size_t off) const { return reinterpret_cast<float*>(d_ws + off); }
+    bool storage16() const { return act_dt != DT_F32; }
 };
 
 namespace flowse {
@@ -192,6 +199,19 @@ static bool in_list(const int32_t* v, int n, int x) {
     for (int i = 0; i < n; ++i)
         if (v[i] == x) return true;
     return false;
+}
+
+// 16-bit storage applies when every wide tensor of the network has a multiple of 32 channels (what the 16-bit
+// matrix-core kernels tile by); otherwise precision 2 / 3 only switch the operands of the big 3x3 convs (fp32 storage).
+static int storage_type_for(const flowse_model* m) {
+    if (m->precision < 2 || getenv("FLOWSE_FP32_STORAGE")) return DT_F32;
+    for (const auto& mod : m->mods) {
+        if (mod.kind == M_RESBLOCK || mod.kind == M_ATTN || mod.kind == M_GN)
+            if ((mod.in_ch % 32) || (mod.out_ch % 32)) return DT_F32;
+        if ((mod.kind == M_COMBINE && (mod.out_ch % 32)) || (mod.kind == M_CONV3 && mod.out_ch != 4 && (mod.out_ch % 32)))
+            return DT_F32;
+    }
+    return m->precision == 2 ? DT_BF16 : DT_F16;
 }
 
 // ---- parameter table helpers
@@ -460,6 +480,7 @@ static int pack_weights(flowse_model* m, const float* blob, Packer& pk) {
             }
         }
     }
+    pk.host.resize((pk.host.size() + 63) & ~(size_t)63, 0.f);      // whole float4s (the 16-bit twin converts by quads)
     return OK;
 }
 
@@ -475,9 +496,11 @@ struct Builder {
     Arena arena;
     int B;
 
-    Tn alloc(int H, int W, int C) {
+    // dt < 0: the model's activation type for wide tensors, fp32 for the 4-channel ones (input pack, pyramids)
+    Tn alloc(int H, int W, int C, int dt = -1) {
         Tn t;
         t.B = B; t.H = H; t.W = W; t.C = C;
+        t.dt = dt >= 0 ? dt : (C > 4 ? m->act_dt : DT_F32);
         t.off = arena.alloc(t.bytes());
         return t;
     }
@@ -523,9 +546,10 @@ struct Builder {
             pnblk[k] = nblk;
             temp[k] = true;
             const size_t t_off = src[k]->off, p_off = poff[k];
+            const int sdt = src[k]->dt;
             op("gn_stats@" + std::to_string(src[k]->H) + "x" + std::to_string(src[k]->W), [=](hipStream_t s) {
-                return launch_gn_stats(M->A(t_off), Ck, nullptr, 0, Bn, HW, M->A(p_off), nblk, s);
-            }, 3.0 * Bn * HW * Ck, 4.0 * Bn * HW * Ck);
+                return launch_gn_stats(M->A(t_off), Ck, nullptr, 0, Bn, HW, M->A(p_off), nblk, s, sdt);
+            }, 3.0 * Bn * HW * Ck, (double)dt_size(sdt) * Bn * HW * Ck);
         }
         GnBuf g;
         g.mean = arena.alloc((size_t)Bn * C * sizeof(float));
@@ -545,12 +569,14 @@ struct Builder {
     // GroupNorm (+ SiLU) materialised into a new tensor.  Small images: statistics finalize and the apply pass are ONE
     // launch (a block per (group, sample) reduces the partials and normalises its HW x C/G elements); otherwise
     // finalize + float4 apply.
-    Tn gn_norm(const Tn& a, const Tn* b2, int64_t w_gamma, int64_t w_beta, bool silu) {
+    // out_dt < 0: same storage type as the input
+    Tn gn_norm(const Tn& a, const Tn* b2, int64_t w_gamma, int64_t w_beta, bool silu, int out_dt = -1) {
         const int C1 = a.C, C2 = b2 ? b2->C : 0, C = C1 + C2, HW = a.H * a.W, Bn = B;
         const int G = std::min(C / 4, 32);
+        const int idt = a.dt, odt = out_dt >= 0 ? out_dt : a.dt;
         if ((int64_t)HW * (C / G) > 8192) {
             GnBuf g = gn(a, b2, w_gamma, w_beta);
-            Tn o = gn_apply(a, b2, g, silu);
+            Tn o = gn_apply(a, b2, g, silu, odt);
             gn_release(g);
             return o;
         }
@@ -573,18 +599,18 @@ struct Builder {
             temp[k] = true;
             const size_t t_off = src[k]->off, p_off = poff[k];
             op("gn_stats@" + std::to_string(src[k]->H) + "x" + std::to_string(src[k]->W), [=](hipStream_t s) {
-                return launch_gn_stats(M->A(t_off), Ck, nullptr, 0, Bn, HW, M->A(p_off), nblk, s);
-            }, 3.0 * Bn * HW * Ck, 4.0 * Bn * HW * Ck);
+                return launch_gn_stats(M->A(t_off), Ck, nullptr, 0, Bn, HW, M->A(p_off), nblk, s, idt);
+            }, 3.0 * Bn * HW * Ck, (double)dt_size(idt) * Bn * HW * Ck);
         }
-        Tn o = alloc(a.H, a.W, C);
+        Tn o = alloc(a.H, a.W, C, odt);
         const size_t a_off = a.off, b_off = b2 ? b2->off : 0, o_off = o.off, p0 = poff[0], p1 = poff[1];
         const int n0 = pnblk[0], n1 = pnblk[1];
         const bool has2 = b2 != nullptr;
         op("gn_norm@" + std::to_string(a.H) + "x" + std::to_string(a.W), [=](hipStream_t s) {
             return launch_gn_finalize_apply(M->A(a_off), M->A(p0), n0, C1, has2 ? M->A(b_off) : nullptr,
                                             has2 ? M->A(p1) : nullptr, n1, C2, Bn, HW, G, M->W(w_gamma), M->W(w_beta),
-                                            1e-6f, silu ? 1 : 0, M->A(o_off), s);
-        }, 8.0 * Bn * HW * C, 8.0 * Bn * HW * C);
+                                            1e-6f, silu ? 1 : 0, M->A(o_off), s, idt, odt);
+        }, 8.0 * Bn * HW * C, (double)(dt_size(idt) + dt_size(odt)) * Bn * HW * C);
         for (int k = 0; k < 2; ++k)
             if (temp[k]) arena.release(poff[k]);
         return o;
@@ -593,30 +619,38 @@ struct Builder {
         arena.release(g.mean);
         arena.release(g.scale);
     }
-    Tn gn_apply(const Tn& a, const Tn* b2, const GnBuf& g, bool silu) {
+    Tn gn_apply(const Tn& a, const Tn* b2, const GnBuf& g, bool silu, int out_dt = -1) {
         flowse_model* M = m;
         const int C1 = a.C, C2 = b2 ? b2->C : 0, HW = a.H * a.W, Bn = B;
-        Tn o = alloc(a.H, a.W, C1 + C2);
+        const int idt = a.dt, odt = out_dt >= 0 ? out_dt : a.dt;
+        Tn o = alloc(a.H, a.W, C1 + C2, odt);
         const size_t a_off = a.off, b_off = b2 ? b2->off : 0, o_off = o.off;
         const bool has2 = b2 != nullptr;
         op("gn_apply@" + std::to_string(a.H) + "x" + std::to_string(a.W), [=](hipStream_t s) {
             GnParams p{M->A(g.mean), M->A(g.scale), M->W(g.beta)};
             return launch_gn_apply(M->A(a_off), C1, has2 ? M->A(b_off) : nullptr, C2, Bn, HW, p, silu ? 1 : 0,
-                                   M->A(o_off), s);
-        }, 8.0 * Bn * HW * (C1 + C2), 8.0 * Bn * HW * (C1 + C2));
+                                   M->A(o_off), s, idt, odt);
+        }, 8.0 * Bn * HW * (C1 + C2), (double)(dt_size(idt) + dt_size(odt)) * Bn * HW * (C1 + C2));
         return o;
     }
     // conv: out (new tensor unless `inplace_res`), res optional
     Tn conv(const std::string& label, const Tn& a, const Tn* b2, int64_t w, int64_t bias, int dense_row0, int Cout,
             int taps, const Tn* res, float scale, bool out_is_res = false, bool cin4 = false,
-            const GnBuf* gin = nullptr, bool gin_silu = false, int64_t wq_off = -1) {
+            const GnBuf* gin = nullptr, bool gin_silu = false, int64_t wq_off = -1, int out_dt = -1) {
         flowse_model* M = m;
-        Tn o = out_is_res ? *res : alloc(a.H, a.W, Cout);
+        Tn o = out_is_res ? *res : alloc(a.H, a.W, Cout, out_dt);
         const int C1 = a.C, C2 = b2 ? b2->C : 0, H = a.H, Wd = a.W, Bn = B;
         const size_t a_off = a.off, b_off = b2 ? b2->off : 0, o_off = o.off, r_off = res ? res->off : 0;
         const bool has2 = b2 != nullptr, hasres = res != nullptr;
-        const int ks = cin4 ? 1 : conv_ksplit(Bn, H, Wd, C1 + C2, Cout, taps);
-        int st_nblk = (cin4 || out_is_res || Cout < 16) ? 0 : conv_fused_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps);
+        const int idt = a.dt, odt = o.dt;
+        const bool in16 = idt != DT_F32;                 // 16-bit storage: the 16-bit matrix-core kernels take it
+        const int ks = cin4 ? 1 : in16 ? (conv_supports_head4(Bn, H, Wd, C1, C2, Cout, taps) || conv16_uses_halo(Bn, H, Wd, C1, C2, Cout, taps)
+                                              ? 1 : conv16_ksplit(Bn, H, Wd, C1 + C2, Cout, taps))
+                                       : conv_ksplit(Bn, H, Wd, C1 + C2, Cout, taps);
+        int st_nblk = (cin4 || out_is_res || Cout < 16) ? 0
+                      : in16 ? (conv16_uses_halo(Bn, H, Wd, C1, C2, Cout, taps) ? H * Wd / 128
+                                                                                 : conv16_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps))
+                             : conv_fused_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps);
         if (cin4 && !out_is_res && C1 == 4 && !has2 && conv_cin4_uses_mfma(Bn, H, Wd, Cout, taps)) st_nblk = H * Wd / 128;
         if (st_nblk > 0) {
             o.st_nblk = st_nblk;
@@ -625,11 +659,11 @@ struct Builder {
         const size_t st_off = o.st_off;
         const bool has_gin = gin != nullptr;
         const GnBuf gbuf = has_gin ? *gin : GnBuf();
-        const bool use_bf16 = wq_off >= 0 && M->precision != 0 && taps == 9 &&
+        const bool use_bf16 = !M->storage16() && wq_off >= 0 && M->precision != 0 && taps == 9 &&
                               conv_supports_bf16(Bn, H, Wd, C1, C2, Cout, taps);
         const int terms = M->precision == 1 ? 3 : 1;
         const auto wino_it = M->wino_of.find(w);
-        const int64_t wino_off = (taps == 9 && !cin4 && wino_it != M->wino_of.end() &&
+        const int64_t wino_off = (!in16 && taps == 9 && !cin4 && wino_it != M->wino_of.end() &&
                                   conv_supports_wino(Bn, H, Wd, C1, C2, Cout, taps)) ? wino_it->second : -1;
         const size_t part_off = ks > 1 ? arena.alloc((size_t)ks * Bn * H * Wd * Cout * sizeof(float)) : 0;
         const size_t table_off = M_table_off;     // by value: the Builder dies before the plan runs
@@ -658,7 +692,13 @@ struct Builder {
                 c.gn = GnParams{M->A(gbuf.mean), M->A(gbuf.scale), M->W(gbuf.beta)};
                 c.gn_silu = gin_silu ? 1 : 0;
             }
-            if (use_bf16) {
+            c.in_dt = idt;
+            c.out_dt = odt;
+            if (in16) {                                   // [Cout][taps][Cin] in the storage type: same offsets as d_w
+                c.wq = M->d_w16 + w;
+                c.terms = 1;
+                c.wq_f16 = idt == DT_F16 ? 1 : 0;
+            } else if (use_bf16) {
                 c.wq = M->d_wq + wq_off;
                 c.terms = terms;
                 c.wq_f16 = M->precision == 3 ? 1 : 0;
@@ -670,8 +710,8 @@ struct Builder {
             return c;
         };
         const double flops = 2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2);
-        const double out_bytes = 4.0 * Bn * H * Wd * Cout * (hasres ? 2 : 1);
-        const double in_bytes = 4.0 * ((double)Bn * H * Wd * (C1 + C2) + (double)Cout * taps * (C1 + C2));
+        const double out_bytes = (double)dt_size(odt) * Bn * H * Wd * Cout * (hasres ? 2 : 1);
+        const double in_bytes = (double)dt_size(idt) * ((double)Bn * H * Wd * (C1 + C2) + (double)Cout * taps * (C1 + C2));
         const double part_bytes = 4.0 * ks * (double)Bn * H * Wd * Cout;
         op(full_label, [=](hipStream_t s) {
             const ConvArgs c = make_args();
@@ -691,8 +731,9 @@ struct Builder {
            Tn* raw_out = nullptr) {
         flowse_model* M = m;
         const int H = a.H, Wd = a.W, C = a.C, Bn = B;
-        Tn o = out_is_add ? *add : (up ? alloc(2 * H, 2 * Wd, C) : alloc(H / 2, Wd / 2, C));
-        if (raw_out) *raw_out = up ? alloc(2 * H, 2 * Wd, C) : alloc(H / 2, Wd / 2, C);
+        const int fdt = a.dt;
+        Tn o = out_is_add ? *add : (up ? alloc(2 * H, 2 * Wd, C, fdt) : alloc(H / 2, Wd / 2, C, fdt));
+        if (raw_out) *raw_out = up ? alloc(2 * H, 2 * Wd, C, fdt) : alloc(H / 2, Wd / 2, C, fdt);
         const size_t a_off = a.off, o_off = o.off, add_off = add ? add->off : 0, r_off = raw_out ? raw_out->off : 0;
         const bool hasg = g != nullptr, hasadd = add != nullptr, hasraw = raw_out != nullptr;
         GnBuf gb = hasg ? *g : GnBuf();
@@ -702,11 +743,11 @@ struct Builder {
             if (hasg) p = GnParams{M->A(gb.mean), M->A(gb.scale), M->W(gb.beta)};
             if (up)
                 return launch_fir_up(M->A(a_off), Bn, H, Wd, C, p, silu ? 1 : 0, hasadd ? M->A(add_off) : nullptr,
-                                     M->A(o_off), s, hasraw ? M->A(r_off) : nullptr);
+                                     M->A(o_off), s, hasraw ? M->A(r_off) : nullptr, fdt);
             return launch_fir_down(M->A(a_off), Bn, H, Wd, C, p, silu ? 1 : 0, M->A(o_off), s,
-                                   hasraw ? M->A(r_off) : nullptr);
+                                   hasraw ? M->A(r_off) : nullptr, fdt);
         }, (up ? 8.0 * 4 : 32.0 / 4) * Bn * H * Wd * C * outs,
-           4.0 * Bn * H * Wd * C * (up ? 1.0 + 4.0 * outs : 1.0 + 0.25 * outs));
+           (double)dt_size(fdt) * Bn * H * Wd * C * (up ? 1.0 + 4.0 * outs : 1.0 + 0.25 * outs));
         return o;
     }
 
@@ -714,8 +755,12 @@ struct Builder {
     Tn resblock(const Module& mod, const Tn& x1, const Tn* x2) {
         const float rs2 = 0.70710678118654752440f;
         Tn h1, xs;
+        auto fusable = [&](const Tn& t, int c2) {       // Conv(act(GroupNorm(t))) as one kernel for this shape?
+            return t.dt != DT_F32 ? conv16_uses_halo(B, t.H, t.W, t.C, c2, mod.out_ch, 9)
+                                  : conv_supports_fused_gn(B, t.H, t.W, t.C, c2, mod.out_ch, 9);
+        };
         if (!mod.up && !mod.down) {
-            if (conv_supports_fused_gn(B, x1.H, x1.W, x1.C, x2 ? x2->C : 0, mod.out_ch, 9)) {
+            if (fusable(x1, x2 ? x2->C : 0)) {
                 // Conv_0(act(GroupNorm_0(x))) in one kernel: the normalised tensor never reaches HBM
                 GnBuf g0 = gn(x1, x2, mod.w_gn0_g, mod.w_gn0_b);
                 h1 = conv("conv0_3x3_gn", x1, x2, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f, false,
@@ -739,7 +784,7 @@ struct Builder {
             release(xr);
         }
         Tn out;
-        if (conv_supports_fused_gn(B, h1.H, h1.W, h1.C, 0, mod.out_ch, 9)) {
+        if (fusable(h1, 0)) {
             GnBuf g1 = gn(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b);
             out = conv("conv1_3x3_gn", h1, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, xs.valid() ? &xs : &x1, rs2,
                        false, false, &g1, true, mod.wq_c1);
@@ -760,15 +805,19 @@ struct Builder {
         flowse_model* M = m;
         const float rs2 = 0.70710678118654752440f;
         const int C = x.C, L = x.H * x.W, Bn = B;
-        Tn hn = gn_norm(x, nullptr, mod.w_gn0_g, mod.w_gn0_b, false);
-        Tn qkv = conv("attn_qkv", hn, nullptr, mod.w_qkv, mod.w_qkv_b, -1, 3 * C, 1, nullptr, 1.f);
+        // the attention sub-block keeps fp32 intermediates in every mode (0.3 % of the FLOPs): GroupNorm widens, the
+        // output projection rounds back to the activation type while adding the skip
+        Tn hn = gn_norm(x, nullptr, mod.w_gn0_g, mod.w_gn0_b, false, DT_F32);
+        Tn qkv = conv("attn_qkv", hn, nullptr, mod.w_qkv, mod.w_qkv_b, -1, 3 * C, 1, nullptr, 1.f, false, false, nullptr,
+                      false, -1, DT_F32);
         release(hn);
-        Tn o = alloc(x.H, x.W, C);
+        Tn o = alloc(x.H, x.W, C, DT_F32);
         const size_t q_off = qkv.off, o_off = o.off;
         op("attention@" + std::to_string(x.H) + "x" + std::to_string(x.W), [=](hipStream_t s) { return launch_attention(M->A(q_off), Bn, L, C, M->A(o_off), s); },
            4.0 * Bn * (double)L * L * C, 16.0 * Bn * L * C);
         release(qkv);
-        Tn out = conv("attn_out", o, nullptr, mod.w_o, mod.w_o_b, -1, C, 1, &x, rs2);
+        Tn out = conv("attn_out", o, nullptr, mod.w_o, mod.w_o_b, -1, C, 1, &x, rs2, false, false, nullptr, false, -1,
+                      x.dt);
         release(o);
         return out;
     }
@@ -878,10 +927,13 @@ static int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
         }
         const Module& gnm = next();
         const Module& pcv = next();
-        const bool pfuse = conv_supports_fused_gn(B, h.H, h.W, h.C, 0, 4, 9);
+        // 16-bit h: the dedicated 4-channel head kernel reads it directly; small images materialise act(GN(h)) in fp32
+        // and run the fp32 kernels
+        const bool pfuse = h.dt != DT_F32 ? conv_supports_head4(B, h.H, h.W, h.C, 0, 4, 9)
+                                          : conv_supports_fused_gn(B, h.H, h.W, h.C, 0, 4, 9);
         GnBuf g;
         if (pfuse) g = bd.gn(h, nullptr, gnm.w_a, gnm.w_a_b);
-        Tn ph = pfuse ? h : bd.gn_norm(h, nullptr, gnm.w_a, gnm.w_a_b, true);
+        Tn ph = pfuse ? h : bd.gn_norm(h, nullptr, gnm.w_a, gnm.w_a_b, true, DT_F32);
         const GnBuf* pg = pfuse ? &g : nullptr;
         if (!pyr.valid()) {
             pyr = bd.conv("pyramid_conv", ph, nullptr, pcv.w_a, pcv.w_a_b, -1, 4, 9, nullptr, 1.f, false, false, pg, true);
@@ -1079,12 +1131,14 @@ static int build_block_plan(flowse_model* m, Plan* plan, int B, int H, int W, in
     const int td = m->temb_dim;
     Tn x1 = bd.alloc(H, W, C1), x2;
     if (C2 > 0) x2 = bd.alloc(H, W, C2);
-    {
-        const size_t o1 = x1.off, o2 = x2.off, n1 = x1.bytes(), n2 = C2 > 0 ? x2.bytes() : 0;
+    {   // the caller's tensors are fp32; in a 16-bit storage mode they are rounded to the activation type on the way in
+        const size_t o1 = x1.off, o2 = x2.off;
+        const int64_t n1 = (int64_t)B * H * W * C1, n2 = C2 > 0 ? (int64_t)B * H * W * C2 : 0;
+        const int d1 = x1.dt, d2 = x2.dt;
         bd.op("block_in", [=](hipStream_t s) {
-            FLOWSE_HIP(hipMemcpyAsync(M->A(o1), M->bcall.in1, n1, hipMemcpyDeviceToDevice, s));
-            if (n2) FLOWSE_HIP(hipMemcpyAsync(M->A(o2), M->bcall.in2, n2, hipMemcpyDeviceToDevice, s));
-            return (int)OK;
+            int rc = launch_convert(M->bcall.in1, DT_F32, M->A(o1), d1, n1, s);
+            if (rc == OK && n2) rc = launch_convert(M->bcall.in2, DT_F32, M->A(o2), d2, n2, s);
+            return rc;
         });
     }
     Tn out;
@@ -1103,11 +1157,10 @@ static int build_block_plan(flowse_model* m, Plan* plan, int B, int H, int W, in
         out = x2;
     }
     {
-        const size_t o = out.off, n = out.bytes();
-        bd.op("block_out", [=](hipStream_t s) {
-            FLOWSE_HIP(hipMemcpyAsync(M->bcall.out, M->A(o), n, hipMemcpyDeviceToDevice, s));
-            return (int)OK;
-        });
+        const size_t o = out.off;
+        const int64_t n = (int64_t)out.B * out.H * out.W * out.C;
+        const int od = out.dt;
+        bd.op("block_out", [=](hipStream_t s) { return launch_convert(M->A(o), od, M->bcall.out, DT_F32, n, s); });
     }
     plan->ws_bytes = bd.arena.peak();
     return OK;
@@ -1123,6 +1176,7 @@ static void free_device_state(flowse_model* m) {
     if (m->d_ws) (void)hipFree(m->d_ws);
     if (m->d_ts) (void)hipFree(m->d_ts);
     if (m->d_wq) (void)hipFree(m->d_wq);
+    if (m->d_w16) (void)hipFree(m->d_w16);
     if (m->d_wino) (void)hipFree(m->d_wino);
     if (m->d_call) (void)hipFree(m->d_call);
     for (hipEvent_t e : m->prof_pool) (void)hipEventDestroy(e);
@@ -1130,7 +1184,8 @@ static void free_device_state(flowse_model* m) {
     m->prof_used = 0;
     m->d_w = nullptr; m->d_ws = nullptr; m->d_ts = nullptr; m->d_wino = nullptr; m->d_call = nullptr;
     m->d_wq = nullptr;
-    m->d_w_numel = m->d_wq_numel = m->d_wino_numel = 0;
+    m->d_w16 = nullptr;
+    m->d_w_numel = m->d_wq_numel = m->d_wino_numel = m->d_w16_numel = 0;
     m->d_ws_bytes = m->d_ts_floats = 0;
     m->device = -1;
     if (sw) (void)hipSetDevice(cur);
@@ -1303,6 +1358,21 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
         m->d_w_numel = (int64_t)pk.host.size();
     }
     FLOWSE_HIP(hipMemcpy(m->d_w, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    m->act_dt = storage_type_for(m);
+    if (m->storage16()) {                    // elementwise 16-bit twin of the packed blob (conv weights keep their offsets)
+        const int64_t n16 = ((int64_t)pk.host.size() + 3) & ~(int64_t)3;
+        if (m->d_w16 && m->d_w16_numel < n16) {
+            FLOWSE_HIP(hipFree(m->d_w16));
+            m->d_w16 = nullptr;
+        }
+        if (!m->d_w16) {
+            FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_w16), n16 * sizeof(uint16_t)));
+            m->d_w16_numel = n16;
+        }
+        const int crc = launch_convert(m->d_w, DT_F32, m->d_w16, m->act_dt, (int64_t)pk.host.size() & ~(int64_t)3, nullptr);
+        if (crc != OK) return crc;
+        pk.wino.clear();                     // no fp32 Winograd kernels run on 16-bit activations
+    }
     // F(2,3) Winograd weights, derived on the device from the packed fp32 weights just uploaded
     m->wino_of.clear();
     int64_t wino_total = 0;
@@ -1327,7 +1397,7 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
     FLOWSE_HIP(hipDeviceSynchronize());
     // optional bf16 planes for the 3x3 ResBlock convolutions the halo kernel can take
     for (auto& mod : m->mods) mod.wq_c0 = mod.wq_c1 = -1;
-    if (m->precision != 0) {
+    if (m->precision != 0 && !m->storage16()) {
         const int terms = m->precision == 1 ? 3 : 1;
         std::vector<uint16_t> q;
         for (auto& mod : m->mods) {

@@ -32,8 +32,9 @@ int gn_partial_blocks(int HW, int C) {
 
 // grid (nblk, B).  Q = C/4 channel quads; PR = 256 / Q pixel lanes (Q <= 256).  Block blk covers pixels
 // [blk * per, min(HW, (blk + 1) * per)) and writes (mean, M2) per channel (see Stat4 in common.h).
-__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __restrict__ in1, int C1,
-                                                              const float* __restrict__ in2, int C2, int HW,
+template <class ST>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const ST* __restrict__ in1, int C1,
+                                                              const ST* __restrict__ in2, int C2, int HW,
                                                               float* __restrict__ partial, int nblk, int per) {
     __shared__ float red[GN_THREADS * 8];
     const int C = C1 + C2, Q = C >> 2;
@@ -46,12 +47,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __res
     st.init();
     if (pr < PR) {
         const int c = cq * 4;
-        const float* src;
+        const ST* src;
         int cs, cc;
         if (c < C1) { src = in1; cs = C1; cc = c; } else { src = in2; cs = C2; cc = c - C1; }
         src += (int64_t)b * HW * cs + cc;
 #pragma unroll 4
-        for (int p = p0 + pr; p < p1; p += PR) st.add(*reinterpret_cast<const float4*>(src + (int64_t)p * cs));
+        for (int p = p0 + pr; p < p1; p += PR) st.add(St<ST>::ld4(src + (int64_t)p * cs));
     }
     st.finish(red + tid * 8);
     __syncthreads();
@@ -143,9 +144,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); }
 
 // grid (ceil(HW * C/4 / 256), B): one float4 per thread, 32-bit index math only
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ in1, int C1,
-                                                       const float* __restrict__ in2, int C2, int HW, GnParams gn,
-                                                       int silu, float* __restrict__ out) {
+template <class ST, class OT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const ST* __restrict__ in1, int C1,
+                                                       const ST* __restrict__ in2, int C2, int HW, GnParams gn,
+                                                       int silu, OT* __restrict__ out) {
     const unsigned C = C1 + C2, Q = C >> 2;
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= (unsigned)HW * Q) return;
@@ -153,8 +155,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const int c = cq * 4, b = blockIdx.y;
     const int64_t pix = (int64_t)b * HW + pix_s;
     float4 v;
-    if (c < C1) v = *reinterpret_cast<const float4*>(in1 + pix * C1 + c);
-    else v = *reinterpret_cast<const float4*>(in2 + pix * C2 + (c - C1));
+    if (c < C1) v = St<ST>::ld4(in1 + pix * C1 + c);
+    else v = St<ST>::ld4(in2 + pix * C2 + (c - C1));
     const float4 mu = *reinterpret_cast<const float4*>(gn.mean + (int64_t)b * C + c);
     const float4 sc = *reinterpret_cast<const float4*>(gn.scale + (int64_t)b * C + c);
     const float4 be = *reinterpret_cast<const float4*>(gn.beta + c);
@@ -164,18 +166,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     o.z = fmaf(v.z - mu.z, sc.z, be.z);
     o.w = fmaf(v.w - mu.w, sc.w, be.w);
     if (silu) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
-    *reinterpret_cast<float4*>(out + pix * C + c) = o;
+    St<OT>::st4(out + pix * C + c, o);
 }
 
 // Small images: finalize and apply in ONE launch.  grid (G, B): the block reduces its group's partials exactly like
 // gn_finalize, then normalises (+ SiLU) the group's HW x cpg elements of cat[in1, in2] into `out`.
-__global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const float* __restrict__ in1, const float* __restrict__ p1,
+template <class ST, class OT>
+__global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const ST* __restrict__ in1, const float* __restrict__ p1,
                                                                int nblk1, int ppb1, int C1,
-                                                               const float* __restrict__ in2, const float* __restrict__ p2,
+                                                               const ST* __restrict__ in2, const float* __restrict__ p2,
                                                                int nblk2, int ppb2, int C2, int HW, int G,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, int silu,
-                                                               float* __restrict__ out) {
+                                                               OT* __restrict__ out) {
     const int g = blockIdx.x, b = blockIdx.y;
     const int C = C1 + C2, cpg = C / G;
     float muf, rstd;
@@ -184,22 +187,23 @@ __global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const float* __r
     for (int i = threadIdx.x; i < n; i += 256) {
         const int pix = i / cpg, c = g * cpg + (i - pix * cpg);
         const int64_t px = (int64_t)b * HW + pix;
-        const float x = c < C1 ? in1[px * C1 + c] : in2[px * C2 + (c - C1)];
+        const float x = c < C1 ? St<ST>::ld1(in1 + px * C1 + c) : St<ST>::ld1(in2 + px * C2 + (c - C1));
         float v = fmaf(x - muf, rstd * gamma[c], beta[c]);
         if (silu) v = silu_f(v);
-        out[px * C + c] = v;
+        St<OT>::st1(out + px * C + c, v);
     }
 }
 
-int launch_gn_stats(const float* in1, int C1, const float* in2, int C2, int B, int HW, float* partial, int nblk,
-                    hipStream_t s) {
+int launch_gn_stats(const void* in1, int C1, const void* in2, int C2, int B, int HW, float* partial, int nblk,
+                    hipStream_t s, int dt) {
     const int C = C1 + C2;
     if ((C1 & 3) || (C2 & 3) || C / 4 > GN_THREADS || C <= 0) {
         set_error("gn_stats: unsupported channels C1=%d C2=%d", C1, C2);
         return ERR_SHAPE;
     }
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(GN_THREADS), 0, s, in1, C1, in2, C2, HW, partial, nblk,
-                       gn_pixels_per_block(HW, nblk));
+    FLOWSE_DT_SWITCH(dt, ST, hipLaunchKernelGGL(gn_stats_kernel<ST>, dim3(nblk, B), dim3(GN_THREADS), 0, s,
+                                                static_cast<const ST*>(in1), C1, static_cast<const ST*>(in2), C2, HW,
+                                                partial, nblk, gn_pixels_per_block(HW, nblk)));
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
@@ -219,30 +223,64 @@ int launch_gn_finalize(const float* partial1, int nblk1, int C1, const float* pa
     return OK;
 }
 
-int launch_gn_finalize_apply(const float* in1, const float* partial1, int nblk1, int C1, const float* in2,
+// out_dt: DT_F32 or the input's storage type
+template <class ST>
+static void launch_gfa(const void* in1, const float* partial1, int nblk1, int ppb1, int C1, const void* in2,
+                       const float* partial2, int nblk2, int ppb2, int C2, int B, int HW, int G, const float* gamma,
+                       const float* beta, float eps, int silu, void* out, int out_dt, hipStream_t s) {
+    if (out_dt == DT_F32)
+        hipLaunchKernelGGL((gn_finalize_apply_kernel<ST, float>), dim3(G, B), dim3(256), 0, s, static_cast<const ST*>(in1),
+                           partial1, nblk1, ppb1, C1, static_cast<const ST*>(in2), partial2, nblk2, ppb2, C2, HW, G, gamma,
+                           beta, eps, silu, static_cast<float*>(out));
+    else
+        hipLaunchKernelGGL((gn_finalize_apply_kernel<ST, ST>), dim3(G, B), dim3(256), 0, s, static_cast<const ST*>(in1),
+                           partial1, nblk1, ppb1, C1, static_cast<const ST*>(in2), partial2, nblk2, ppb2, C2, HW, G, gamma,
+                           beta, eps, silu, static_cast<ST*>(out));
+}
+
+int launch_gn_finalize_apply(const void* in1, const float* partial1, int nblk1, int C1, const void* in2,
                              const float* partial2, int nblk2, int C2, int B, int HW, int G, const float* gamma,
-                             const float* beta, float eps, int silu, float* out, hipStream_t s) {
+                             const float* beta, float eps, int silu, void* out, hipStream_t s, int in_dt, int out_dt) {
     const int ppb1 = gn_pixels_per_block(HW, nblk1), ppb2 = nblk2 > 0 ? gn_pixels_per_block(HW, nblk2) : 1;
     const int C = C1 + C2;
     if (C % G != 0 || (C2 > 0 && (!partial2 || !in2))) {
         set_error("gn_finalize_apply: unsupported C=%d G=%d", C, G);
         return ERR_SHAPE;
     }
-    hipLaunchKernelGGL(gn_finalize_apply_kernel, dim3(G, B), dim3(256), 0, s, in1, partial1, nblk1, ppb1, C1, in2, partial2,
-                       nblk2, ppb2, C2, HW, G, gamma, beta, eps, silu, out);
+    if (out_dt != DT_F32 && out_dt != in_dt) {
+        set_error("gn_finalize_apply: output type must be fp32 or the input type");
+        return ERR_ARG;
+    }
+    FLOWSE_DT_SWITCH(in_dt, ST, launch_gfa<ST>(in1, partial1, nblk1, ppb1, C1, in2, partial2, nblk2, ppb2, C2, B, HW, G,
+                                               gamma, beta, eps, silu, out, out_dt, s));
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
 
-int launch_gn_apply(const float* in1, int C1, const float* in2, int C2, int B, int HW, GnParams gn, int silu,
-                    float* out, hipStream_t s) {
+template <class ST>
+static void launch_ga(const void* in1, int C1, const void* in2, int C2, int B, int HW, GnParams gn, int silu, void* out,
+                      int out_dt, unsigned gx, hipStream_t s) {
+    if (out_dt == DT_F32)
+        hipLaunchKernelGGL((gn_apply_kernel<ST, float>), dim3(gx, B), dim3(256), 0, s, static_cast<const ST*>(in1), C1,
+                           static_cast<const ST*>(in2), C2, HW, gn, silu, static_cast<float*>(out));
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<ST, ST>), dim3(gx, B), dim3(256), 0, s, static_cast<const ST*>(in1), C1,
+                           static_cast<const ST*>(in2), C2, HW, gn, silu, static_cast<ST*>(out));
+}
+
+int launch_gn_apply(const void* in1, int C1, const void* in2, int C2, int B, int HW, GnParams gn, int silu,
+                    void* out, hipStream_t s, int in_dt, int out_dt) {
     const int64_t per_sample = (int64_t)HW * ((C1 + C2) / 4);
     if (per_sample >= (1LL << 32) || B > 65535) {
         set_error("gn_apply: tensor too large");
         return ERR_SHAPE;
     }
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((per_sample + 255) / 256), B), dim3(256), 0, s, in1, C1, in2, C2,
-                       HW, gn, silu, out);
+    if (out_dt != DT_F32 && out_dt != in_dt) {
+        set_error("gn_apply: output type must be fp32 or the input type");
+        return ERR_ARG;
+    }
+    FLOWSE_DT_SWITCH(in_dt, ST, launch_ga<ST>(in1, C1, in2, C2, B, HW, gn, silu, out, out_dt,
+                                              (unsigned)((per_sample + 255) / 256), s));
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }

@@ -184,8 +184,9 @@ class Block:
         self.names, self.shapes, self.offsets = handle_param_table(self.h)
         self.kind, self.out_ch, self.up, self.down = kind, out_ch, up, down
 
-    def load(self, weights):
-        """weights: {module-local reference key (e.g. 'Conv_0.weight'): tensor}"""
+    def load(self, weights, precision="fp32"):
+        """weights: {module-local reference key (e.g. 'Conv_0.weight'): tensor}; precision as NCSNpp.set_precision"""
+        _lib.check(L.flowse_model_set_precision(self.h, {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}[precision]))
         blob = torch.zeros(int(L.flowse_model_blob_numel(self.h)))
         for n, shp, off in zip(self.names, self.shapes, self.offsets):
             w = weights[n[len("all_modules.0."):]].float()

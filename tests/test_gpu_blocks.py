@@ -83,3 +83,64 @@ def test_block_handle_rejects_misuse():
     x = torch.zeros(1, 8, 8, 32, device="cuda")
     with pytest.raises(_lib.FlowseError):                                                 # weights not loaded
         _lib.check(_lib.lib.flowse_block_forward(blk.h, _lib.ptr(x), 32, None, _lib.ptr(x), _lib.ptr(x), 1, 8, 8, None))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 16-bit STORAGE modes (BASELINE configs 3 / 5): activations between kernels are bf16 / half, products on the 16-bit
+# matrix cores, accumulation and GroupNorm statistics in fp32.  Every module variant, at shapes that take each kernel
+# family (LDS-halo 3x3 with fused GroupNorm, flat 1x1 / 3x3, split-K, FIR, 4-channel heads), against the fp32 CPU oracle.
+# The reference has no 16-bit path; the bounds are what 8 (bf16) / 11 (half) mantissa bits give for one module and are
+# asserted as measured ceilings, not as parity with the reference.
+MODES16 = [("bf16", 2.5e-2), ("fp16", 3.5e-3)]
+CASES16 = [  # tag, cin, cout, (B, C, H, W), kwargs, two-source split
+    ("plain_halo", 128, 128, (2, 128, 64, 128), {}, None),
+    ("concat_halo_shortcut", 256, 128, (2, 256, 64, 128), {}, 128),
+    ("concat384_straddle", 384, 128, (2, 384, 64, 128), {}, 256),
+    ("small_flat_splitk", 256, 256, (2, 256, 8, 8), {}, None),
+    ("tiny_4x4_concat", 512, 256, (2, 512, 4, 4), {}, 256),
+    ("down", 128, 128, (2, 128, 64, 64), dict(down=True), None),
+    ("up", 256, 256, (2, 256, 16, 16), dict(up=True), None),
+]
+
+
+@pytest.mark.parametrize("mode,bound", MODES16)
+@pytest.mark.parametrize("tag,cin,cout,shp,kw,split", CASES16)
+def test_resblock_16bit_storage_vs_oracle(tag, cin, cout, shp, kw, split, mode, bound):
+    import _gpu as G
+    from oracle import ncsnpp_oracle as O
+    sc = True if kw else None
+    keys = C.resblock_keys(cin, cout, 512, sc)
+    wl = _weights(keys, f"b16.{tag}.")
+    blk = G.Block("resnet", cin, cout, temb_dim=512, **kw).load(wl, precision=mode)
+    x = torch.from_numpy(synth.normal(7, 11, shp))
+    temb = torch.from_numpy(synth.normal(7, 12, (shp[0], 512)))
+    ref = O.resblock(O._W({f"all_modules.0.{k}": v for k, v in wl.items()}), 0, x, temb, **kw)
+    got = blk(x, temb=temb) if split is None else blk(x[:, :split].contiguous(), x[:, split:].contiguous(), temb=temb)
+    err = C.rel_l2(got, ref)
+    print(f"resblock {tag} {mode}: rel-L2 vs fp32 oracle {err:.3e}")
+    assert got.shape == ref.shape and err < bound
+
+
+@pytest.mark.parametrize("mode,bound", MODES16)
+def test_attnblock_16bit_storage_vs_oracle(mode, bound):
+    import _gpu as G
+    from oracle import ncsnpp_oracle as O
+    wl = _weights(C.attn_keys(256), "b16.attn.")
+    blk = G.Block("attn", 256, 256).load(wl, precision=mode)
+    x = torch.from_numpy(synth.normal(7, 13, (2, 256, 16, 16)))
+    ref = O.attnblock(O._W({f"all_modules.0.{k}": v for k, v in wl.items()}), 0, x)
+    err = C.rel_l2(blk(x), ref)
+    print(f"attnblock {mode}: rel-L2 vs fp32 oracle {err:.3e}")
+    assert err < bound
+
+
+def test_16bit_storage_falls_back_when_channels_do_not_tile():
+    """Channel counts that are not multiples of 32 keep fp32 storage (precision then only selects operand types where a
+    16-bit kernel applies): results stay fp32-class."""
+    import _gpu as G
+    g = C.gold("op_rb_widen")
+    blk = G.Block("resnet", 48, 32, temb_dim=64).load(_weights(C.resblock_keys(48, 32, 64, None), "rb_widen."),
+                                                     precision="bf16")
+    x = torch.from_numpy(synth.normal(5, 5, (2, 48, 16, 8)))
+    temb = torch.from_numpy(synth.normal(5, 4, (2, 64)))
+    assert C.rel_l2(blk(x, temb=temb), g["out"]) < TOL
