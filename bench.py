@@ -331,7 +331,8 @@ def main():
             alts = {}
             for mode in ("bf16x3", "bf16", "fp16"):
                 model.dnn.set_precision(mode)
-                xm = step()
+                for _ in range(2):                             # eager pass + graph capture
+                    xm = step()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(args.steps):
@@ -340,7 +341,28 @@ def main():
                 dt_m = time.perf_counter() - t1
                 err = float((xm - ref_x).abs().pow(2).sum().sqrt() / ref_x.abs().pow(2).sum().sqrt())
                 alts[mode] = {"value": args.steps * B * T / dt_m, "unit": "frames/s", "ms_per_step": 1e3 * dt_m / args.steps,
-                              "rel_l2_vs_fp32_mode": err}
+                              "rel_l2_vs_fp32_mode": err,
+                              "storage": "fp32 activations, split-bf16 operands in the 3x3 convs" if mode == "bf16x3"
+                                         else f"{mode} activations in HBM, {mode} matrix-core operands, fp32 accumulate / GroupNorm"}
+                # the mode's own dominant kernel (3x3 conv with fused GroupNorm input) against BOTH roofs
+                model.dnn.profile_begin(0)
+                step()
+                torch.cuda.synchronize()
+                pm = model.dnn.profile_end()
+                dm = pm.get("dominant_conv3x3")
+                if dm and dm["ms"] > 0:
+                    tf = dm["issued"] / (dm["ms"] * 1e-3) / 1e12
+                    gbs = dm["bytes"] / (dm["ms"] * 1e-3) / 1e9
+                    alts[mode]["roofline"] = {
+                        "kernel": "flowse::conv3x3_halo_bf16_kernel (LDS-halo 3x3, 16-bit MFMA operands, fused GroupNorm+SiLU input)",
+                        "bound": "hbm" if gbs / HBM_PEAK_GBS > tf / PEAK_16BIT_MATRIX_TFLOPS else "mfma",
+                        "achieved_TFLOPs_issued": tf, "mfma_peak_TFLOPs": PEAK_16BIT_MATRIX_TFLOPS,
+                        "mfma_frac": tf / PEAK_16BIT_MATRIX_TFLOPS,
+                        "achieved_GBs_algorithmic": gbs, "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac": gbs / HBM_PEAK_GBS,
+                        "launches": dm["launches"], "avg_launch_ms": dm["ms"] / dm["launches"]}
+                    tot = pm.get("_all_launches")
+                    if tot:
+                        alts[mode]["roofline"]["whole_path_issued_TFLOPs"] = tot["issued"] / (dt_m / args.steps) / 1e12
             model.dnn.set_precision("fp32")
             out["alt_precision"] = alts
         if world == 1 and not args.no_cpu_baseline:

@@ -63,6 +63,8 @@ SIGNATURES = {
     "flowse_profile_end": (_i, [_vp, C.c_char_p, _i]),
     "flowse_upfirdn2d": (_i, [_fp, _fp] + [_i] * 13 + [_fp, _i, _i, _vp]),
     "flowse_op_conv2d": (_i, [_fp, _i, _fp, _i, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _vp]),
+    "flowse_op_conv2d_16": (_i, [_fp, _i, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _f, _i, _vp, _i64,
+                                _vp]),
     "flowse_op_conv2d_scratch_floats": (_i64, [_i, _i, _i, _i, _i, _i]),
     "flowse_op_conv3x3_gn": (_i, [_fp, _i, _fp, _i, _fp, _fp, _f, _i, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _fp, _vp]),
     "flowse_op_conv3x3_f23": (_i, [_fp, _i, _fp, _i, _fp, _fp, _f, _i, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _fp, _vp]),

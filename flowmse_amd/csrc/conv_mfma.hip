@@ -520,10 +520,13 @@ __device__ __forceinline__ u32x4 buf_ld_quad(__amdgpu_buffer_rsrc_t r, unsigned 
         if constexpr (std::is_same<ST, bf16_t>::value) {
             o.x = t.x << 16; o.y = t.x & 0xffff0000u; o.z = t.y << 16; o.w = t.y & 0xffff0000u;
         } else {
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            const h2 a = __builtin_bit_cast(h2, t.x), b = __builtin_bit_cast(h2, t.y);
-            o.x = __float_as_uint((float)a.x); o.y = __float_as_uint((float)a.y);
-            o.z = __float_as_uint((float)b.x); o.w = __float_as_uint((float)b.y);
+            // (element-wise bit casts: a bit cast of the dword to a 2 x half vector was miscompiled by hipcc 7.2 here)
+            const _Float16 e0 = __builtin_bit_cast(_Float16, (unsigned short)(t.x & 0xffffu));
+            const _Float16 e1 = __builtin_bit_cast(_Float16, (unsigned short)(t.x >> 16));
+            const _Float16 e2 = __builtin_bit_cast(_Float16, (unsigned short)(t.y & 0xffffu));
+            const _Float16 e3 = __builtin_bit_cast(_Float16, (unsigned short)(t.y >> 16));
+            o.x = __float_as_uint((float)e0); o.y = __float_as_uint((float)e1);
+            o.z = __float_as_uint((float)e2); o.w = __float_as_uint((float)e3);
         }
         return o;
     }
@@ -2119,7 +2122,8 @@ __global__ __launch_bounds__(256, 2) void conv_flat16_kernel(ConvArgs a) {
 // CUs; everything else goes to the flat kernel, sliced along K (two-step stages, >= 2 stages per slice) until ~512
 // blocks exist.
 bool conv16_uses_halo(int B, int H, int W, int C1, int C2, int Cout, int taps) {
-    if (taps != 9 || (H & 7) || (W & 15) || (C1 % KC) || (C2 % KC) || (Cout % 128)) return false;
+    static const bool off = getenv("FLOWSE_NO_HALO16") != nullptr;         // test / A-B hook: everything on the flat kernel
+    if (off || taps != 9 || (H & 7) || (W & 15) || (C1 % KC) || (C2 % KC) || (Cout % 128)) return false;
     const int64_t cmax = C1 > C2 ? C1 : C2;
     if ((int64_t)(9 * W + 18) * cmax * 4 >= (1LL << 31) || (int64_t)Cout * 9 * (C1 + C2) * 4 >= (1LL << 31)) return false;
     return ((int64_t)B * H * W / 128) * (Cout / 128) >= 128;

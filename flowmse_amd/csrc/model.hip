@@ -717,7 +717,7 @@ struct Builder {
             const ConvArgs c = make_args();
             return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s, false);
         }, flops, in_bytes + (ks > 1 ? part_bytes : out_bytes), has_gin && Cout > 64,
-           wino_off >= 0 ? flops * (conv_wino_default_f43() ? 0.5 : 2.0 / 3.0) : flops);
+           wino_off >= 0 ? flops * (conv_wino_default_f43() ? 0.5 : 2.0 / 3.0) : (use_bf16 && terms == 3) ? 3.0 * flops : flops);
         if (ks > 1)
             op("splitk_reduce@" + std::to_string(H) + "x" + std::to_string(Wd), [=](hipStream_t s) { return launch_splitk_reduce(make_args(), s); }, 0.0,
                part_bytes + out_bytes);
@@ -1742,6 +1742,66 @@ int flowse_op_conv3x3_f43(const float* in1, int C1, const float* in2, int C2, co
                           void* stream) {
     return op_conv3x3_winograd(1, in1, C1, in2, C2, gamma, beta, eps, silu, w, bias, bias2, bias2_stride, res, out, B, H,
                                W, Cout, scale, scratch, stream);
+}
+
+// 16-bit storage per-op entry: fp32 NHWC tensors at the boundary, rounded to bf16 (dt 1) / half (dt 2) inside, conv on
+// the 16-bit matrix cores (LDS-halo kernel when it applies, else the flat kernel), result widened back.  Optional fused
+// GroupNorm(+SiLU) on the input (halo shapes only) from caller-supplied per-(sample, channel) mean / scale and beta.
+int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
+                        const float* res, const float* gn_mean, const float* gn_scale, const float* gn_beta, int silu,
+                        float* out, int B, int H, int W, int Cout, int taps, float scale, int dt, void* scratch,
+                        int64_t scratch_bytes, void* stream) {
+    if (!in1 || !w || !out || !scratch || (dt != DT_BF16 && dt != DT_F16) || (taps != 1 && taps != 9)) {
+        set_error("flowse_op_conv2d_16: bad argument");
+        return ERR_ARG;
+    }
+    if (!in2) C2 = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t M = (int64_t)B * H * W, C = C1 + C2;
+    const bool halo = conv16_uses_halo(B, H, W, C1, C2, Cout, taps);
+    const int ks = halo ? 1 : conv16_ksplit(B, H, W, (int)C, Cout, taps);
+    const int64_t nw = ((int64_t)Cout * taps * C + 3) & ~(int64_t)3;
+    int64_t need = 2 * (M * C1 + M * C2 + nw + 2 * M * Cout) + 64 + (ks > 1 ? 4 * (int64_t)ks * M * Cout : 0);
+    if (scratch_bytes < need + 256) {
+        set_error("flowse_op_conv2d_16: scratch needs %lld bytes", (long long)(need + 256));
+        return ERR_ARG;
+    }
+    if (gn_mean && !halo) {
+        set_error("flowse_op_conv2d_16: fused GroupNorm input only on LDS-halo shapes");
+        return ERR_SHAPE;
+    }
+    char* p = static_cast<char*>(scratch);
+    auto take = [&](int64_t bytes) { char* q = p; p += (bytes + 255) & ~(int64_t)255; return q; };
+    void* a1 = take(2 * M * C1);
+    void* a2 = C2 ? take(2 * M * C2) : nullptr;
+    void* wq = take(2 * nw);
+    void* r16 = res ? take(2 * M * Cout) : nullptr;
+    void* o16 = take(2 * M * Cout);
+    float* part = ks > 1 ? reinterpret_cast<float*>(take(4 * (int64_t)ks * M * Cout)) : nullptr;
+    if ((size_t)(p - static_cast<char*>(scratch)) > (size_t)scratch_bytes) {
+        set_error("flowse_op_conv2d_16: scratch too small");
+        return ERR_ARG;
+    }
+    int rc = launch_convert(in1, DT_F32, a1, dt, M * C1, s);
+    if (rc == OK && C2) rc = launch_convert(in2, DT_F32, a2, dt, M * C2, s);
+    if (rc == OK) rc = launch_convert(w, DT_F32, wq, dt, nw, s);
+    if (rc == OK && res) rc = launch_convert(res, DT_F32, r16, dt, M * Cout, s);
+    if (rc != OK) return rc;
+    ConvArgs c;
+    c.in1 = static_cast<const float*>(a1); c.in2 = static_cast<const float*>(a2); c.C1 = C1; c.C2 = C2;
+    c.w = w; c.bias = bias; c.bias2 = nullptr; c.bias2_stride = 0;
+    c.res = static_cast<const float*>(r16); c.out = static_cast<float*>(o16);
+    c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = taps; c.scale = scale;
+    c.ksplit = ks; c.partial = part;
+    c.wq = wq; c.terms = 1; c.wq_f16 = dt == DT_F16 ? 1 : 0;
+    c.in_dt = dt; c.out_dt = dt;
+    if (gn_mean) {
+        c.gn = GnParams{gn_mean, gn_scale, gn_beta};
+        c.gn_silu = silu;
+    }
+    rc = launch_conv(c, s);
+    if (rc != OK) return rc;
+    return launch_convert(o16, dt, out, DT_F32, M * Cout, s);
 }
 
 int flowse_op_fir_up(const float* in, float* out, int B, int H, int W, int C, void* stream) {

@@ -183,6 +183,16 @@ int flowse_op_conv2d(const float* in1, int C1, const float* in2, int C2, const f
  * `splitk_scratch` holds flowse_op_conv2d_scratch_floats(...) floats (0 = this shape never splits); with
  * splitk_scratch == NULL the single-pass kernel is used. */
 int64_t flowse_op_conv2d_scratch_floats(int B, int H, int W, int Cin, int Cout, int taps);
+/* The same contract on the 16-bit matrix cores with 16-bit activation storage (BASELINE configs 3 / 5; dt 1 = bf16,
+ * 2 = IEEE half): the fp32 tensors are rounded to dt on the way in, the conv runs as in the 16-bit modes of the model
+ * handle (LDS-halo kernel for 3x3 shapes it covers, flat kernel (+ split-K) otherwise), the result is widened back.
+ * Optional fused GroupNorm(+SiLU) of the input from per-(sample, channel) gn_mean / gn_scale [B][C1+C2] and gn_beta
+ * [C1+C2] (LDS-halo shapes only).  `scratch`: device memory, >= 2*(in + w + res + 2*out elements) + 4*ksplit*out
+ * elements + 4 KB bytes. */
+int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
+                        const float* res, const float* gn_mean, const float* gn_scale, const float* gn_beta, int silu,
+                        float* out, int B, int H, int W, int Cout, int taps, float scale, int dt, void* scratch,
+                        int64_t scratch_bytes, void* stream);
 /* Fused ResnetBlock half:  out = (conv3x3(act(GroupNorm(cat[in1,in2]))) + bias + bias2[b] + res) * scale
  * (layerspp.py:246-249 / :265-267) with the normalisation + SiLU applied while the input tile is staged into LDS.
  * Only for shapes the halo kernel covers (H % 8 == 0, W % 16 == 0, C1 % 32 == 0, C2 % 32 == 0, image large

@@ -335,3 +335,59 @@ def test_stft_istft_fused_vs_torch(G, Ls, scale):
     ref_back = st.istft(st.spec_back(ref), Ls) * (1.0 / scale)
     back = G.istft_decompress(Y, T, Ls, 1.0 / scale)
     assert C.rel_l2(back, ref_back) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 16-bit storage convolution (flowse_op_conv2d_16): fp32 tensors at the boundary, bf16 / half activations + weights and
+# the 16-bit matrix cores inside.  Reference = torch fp32 conv of the UNROUNDED tensors, so the bound is the storage
+# type's rounding (bf16 2^-9, half 2^-12 per operand) through a K-term sum -- asserted as a measured ceiling.
+def _conv16(x, w, dt, bias=None, x2=None, res=None, gn=None, scale=1.0):
+    import _gpu as G
+    from flowmse_amd import _lib
+    L = _lib.lib
+    Cout, Cin, k, _ = w.shape
+    taps = k * k
+    a1 = G.nhwc(x)
+    a2 = G.nhwc(x2) if x2 is not None else None
+    B, H, W, C1 = a1.shape
+    C2 = a2.shape[3] if a2 is not None else 0
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, taps, Cin).contiguous().cuda()
+    bb = bias.cuda() if bias is not None else None
+    rr = G.nhwc(res) if res is not None else None
+    mean = scl = beta = None
+    if gn is not None:
+        mean, scl, beta = (t.contiguous().cuda() for t in gn)
+    out = torch.empty(B, H, W, Cout, device="cuda")
+    scratch = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    _lib.check(L.flowse_op_conv2d_16(_lib.ptr(a1), C1, _lib.ptr(a2), C2, _lib.ptr(wp), _lib.ptr(bb), _lib.ptr(rr),
+                                     _lib.ptr(mean), _lib.ptr(scl), _lib.ptr(beta), 1, _lib.ptr(out), B, H, W, Cout, taps,
+                                     float(scale), dt, _lib.ptr(scratch), scratch.numel(), G.stream()))
+    torch.cuda.synchronize()
+    return G.nchw(out)
+
+
+@pytest.mark.parametrize("dt,bound", [(1, 4e-3), (2, 5e-4)])
+@pytest.mark.parametrize("case", ["halo", "halo_gn_concat", "halo_32ch", "flat_small_splitk", "flat_1x1_concat", "flat_w8"])
+def test_conv2d_16bit_storage(case, dt, bound):
+    g = torch.Generator().manual_seed(3)
+    shapes = {"halo": (2, 128, 0, 128, 64, 128, 3), "halo_gn_concat": (2, 128, 128, 128, 64, 128, 3),
+              "halo_32ch": (2, 32, 0, 128, 64, 128, 3), "flat_small_splitk": (2, 256, 0, 256, 16, 16, 3),
+              "flat_1x1_concat": (2, 256, 128, 128, 32, 64, 1), "flat_w8": (3, 256, 0, 256, 8, 8, 3)}
+    B, C1, C2, Cout, H, W, k = shapes[case]
+    C = C1 + C2
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Cout, C, k, k, generator=g) / (C * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    gn, xin = None, x
+    if case == "halo_gn_concat":
+        mean = 0.2 * torch.randn(B, C, generator=g)
+        scl = 1 + 0.2 * torch.randn(B, C, generator=g)
+        beta = 0.2 * torch.randn(C, generator=g)
+        gn = (mean, scl, beta)
+        xin = F.silu((x - mean[:, :, None, None]) * scl[:, :, None, None] + beta[None, :, None, None])
+    ref = (F.conv2d(xin, w, bias, padding=k // 2) + res) * 0.7071
+    got = _conv16(x[:, :C1].contiguous(), w, dt, bias, x[:, C1:].contiguous() if C2 else None, res, gn, 0.7071)
+    err = float((got - ref).norm() / ref.norm())
+    print(f"conv2d_16 {case} dt={dt}: rel-L2 vs fp32 torch {err:.3e}")
+    assert err < bound
