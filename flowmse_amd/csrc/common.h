@@ -93,6 +93,51 @@ template <> struct St<f16_t> {
         p->v = __builtin_bit_cast(unsigned short, x);
     }
 };
+// 16 bytes of consecutive elements: 4 floats, or 8 x 16 bit (widened into v[0..7])
+template <class ST> struct Vec16 { static constexpr int N = 16 / (int)sizeof(ST); };
+template <class ST>
+__device__ __forceinline__ void ld16(const ST* p, float* v) {
+    if constexpr (sizeof(ST) == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (St<ST>::dt == DT_BF16) {
+                v[2 * i] = __uint_as_float(w[i] << 16);
+                v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+            } else {
+                v[2 * i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[i] & 0xffffu));
+                v[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[i] >> 16));
+            }
+        }
+    }
+}
+// stores v[0..N) rounded to ST and leaves the rounded values (as read back later) in v
+template <class ST>
+__device__ __forceinline__ void st16_round(ST* p, float* v) {
+    if constexpr (sizeof(ST) == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (St<ST>::dt == DT_BF16) {
+                w[i] = St<bf16_t>::pack2(v[2 * i], v[2 * i + 1]);
+                v[2 * i] = __uint_as_float(w[i] << 16);
+                v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+            } else {
+                const _Float16 a = (_Float16)v[2 * i], b = (_Float16)v[2 * i + 1];
+                w[i] = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+                v[2 * i] = (float)a;
+                v[2 * i + 1] = (float)b;
+            }
+        }
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
 // run `F.template operator()<ST>()` for the storage type tagged dt
 #define FLOWSE_DT_SWITCH(dt, ST, ...)                                          \
     switch (dt) {                                                              \
@@ -200,6 +245,7 @@ struct ConvArgs {
     // and by the 4-channel heads; 16-bit outputs by those plus the 4-channel input convs, the fp32 flat kernel
     // (attention output projection) and the split-K reductions.
     int in_dt = DT_F32, out_dt = DT_F32;
+    int dbg = 0;        // timing ablations of the 16-bit halo kernel (FLOWSE_ABL16 bit mask; results are wrong when set)
 };
 // K slices of the 16-bit flat kernel for a shape (its own policy: no Winograd alternative, two K steps per stage)
 int conv16_ksplit(int B, int H, int W, int Cin, int Cout, int taps);

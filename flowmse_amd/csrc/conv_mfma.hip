@@ -202,6 +202,127 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     });
 }
 
+// ---- output stage for one [128 tile rows = 8 x 16 pixels][64 channels] fp32 tile sitting in LDS (row pitch CROW floats).
+// Thread = (row lane, 16-byte channel group): bias + per-sample bias + residual + scale, ONE rounding to OT, 16-byte
+// loads / stores (4 floats or 8 x 16 bit per lane: half the memory instructions of an 8-byte form for the 16-bit types),
+// and the GroupNorm partial statistics (mean, M2 per channel over the 128 pixels) of exactly what was stored.  The
+// statistics are pivoted per thread and merged with Chan's formula for EQUAL counts -- lane shuffles inside a wave, one
+// LDS hop across the four waves -- so there is no division and no serial merge loop.  `red`: 4 x 64 x 2 floats of LDS
+// scratch.  All 256 threads must call; Cs must be complete (barrier before) and may be overwritten after the call's
+// last barrier.
+template <class OT>
+__device__ __forceinline__ void tile128x64_out(const ConvArgs& a, const float* Cs, int CROW, float* red, int m_tl, int W,
+                                               int n_base, int bsmp, int tile) {
+    constexpr int CPT = Vec16<OT>::N, TPR = 64 / CPT, RPP = 256 / TPR, NRW = 128 / RPP;
+    const int tid = threadIdx.x;
+    const int ec = tid % TPR, er0 = tid / TPR;
+    const int n = n_base + ec * CPT;
+    const OT* resb = reinterpret_cast<const OT*>(a.res) + (int64_t)m_tl * a.Cout + n;
+    OT* outb = reinterpret_cast<OT*>(a.out) + (int64_t)m_tl * a.Cout + n;
+    const bool has_res = a.res != nullptr;
+    float bq[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) bq[j] = 0.f;
+    if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) bq[j] = a.bias[n + j];
+    }
+    if (a.bias2) {
+        const float* b2 = a.bias2 + (int64_t)bsmp * a.bias2_stride + n;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) bq[j] += b2[j];
+    }
+    float piv[CPT], s1[CPT], s2[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) { piv[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+    constexpr int GRP = NRW < 4 ? NRW : 4;               // rows per batch: their residuals are requested together
+#pragma unroll
+    for (int g0 = 0; g0 < NRW; g0 += GRP) {
+        float rres[GRP][CPT];
+        int roff[GRP];
+#pragma unroll
+        for (int k = 0; k < GRP; ++k) {
+            const int rr = er0 + (g0 + k) * RPP;
+            roff[k] = ((rr >> 4) * W + (rr & 15)) * a.Cout;
+            if (has_res) ld16<OT>(resb + roff[k], rres[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < GRP; ++k) {
+            const int rr = er0 + (g0 + k) * RPP;
+            float v[CPT];
+#pragma unroll
+            for (int q = 0; q < CPT / 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(Cs + rr * CROW + ec * CPT + q * 4);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                float t = v[j] + bq[j];
+                if (has_res) t += rres[k][j];
+                v[j] = t * a.scale;
+            }
+            st16_round<OT>(outb + roff[k], v);
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                if (g0 + k == 0) piv[j] = v[j];
+                const float d = v[j] - piv[j];
+                s1[j] += d;
+                s2[j] = fmaf(d, d, s2[j]);
+            }
+        }
+    }
+    if (!a.stats) return;
+    // per-thread (mean, M2) over NRW rows, then equal-count merges: lanes with equal `ec` inside the wave, then waves
+    float cnt = (float)NRW;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const float mean = piv[j] + s1[j] * (1.f / NRW);
+        const float m2 = fmaxf(s2[j] - s1[j] * s1[j] * (1.f / NRW), 0.f);
+        piv[j] = mean;
+        s2[j] = m2;
+    }
+#pragma unroll
+    for (int off = TPR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const float mo = __shfl_xor(piv[j], off), qo = __shfl_xor(s2[j], off);
+            const float d = mo - piv[j];
+            s2[j] = s2[j] + qo + d * d * (0.5f * cnt);
+            piv[j] = 0.5f * (piv[j] + mo);
+        }
+        cnt *= 2.f;
+    }
+    const int wave = tid >> 6;
+    if ((tid & 63) < TPR) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            red[(wave * 64 + ec * CPT + j) * 2] = piv[j];
+            red[(wave * 64 + ec * CPT + j) * 2 + 1] = s2[j];
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {                                       // one thread per channel: ((w0 + w1) + (w2 + w3)), 32 pixels each
+        float m01, q01, m23, q23;
+        {
+            const float ma = red[tid * 2], qa = red[tid * 2 + 1], mb = red[(64 + tid) * 2], qb = red[(64 + tid) * 2 + 1];
+            const float d = mb - ma;
+            m01 = 0.5f * (ma + mb);
+            q01 = qa + qb + d * d * 16.f;
+        }
+        {
+            const float ma = red[(128 + tid) * 2], qa = red[(128 + tid) * 2 + 1], mb = red[(192 + tid) * 2],
+                        qb = red[(192 + tid) * 2 + 1];
+            const float d = mb - ma;
+            m23 = 0.5f * (ma + mb);
+            q23 = qa + qb + d * d * 16.f;
+        }
+        const float d = m23 - m01;
+        float* dst = a.stats + (((int64_t)bsmp * a.stats_nblk + tile) * a.Cout + n_base + tid) * 2;
+        dst[0] = 0.5f * (m01 + m23);
+        dst[1] = q01 + q23 + d * d * 32.f;
+    }
+}
+
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
@@ -1360,7 +1481,7 @@ static int launch_head4(const ConvArgs& a, hipStream_t s) {
 // error of the 1-D F(4,3) form is ~3x the direct sum's (6e-7 vs 2e-7 rel-L2 on unit-variance data).
 constexpr int F43_HROW = 18 * LDS_ROW + 8;    // words per halo pixel row: 4 rows = 0 mod 64 banks (quad 1 vs quad 0)
 
-template <int GN, int CH>
+template <int GN, int CH, bool SPLIT>
 __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem) {
     constexpr int BN = 64;
     constexpr int HROWS = 180;                           // 10 x 18 halo pixels
@@ -1594,7 +1715,7 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     // This wave's half of A^T m, laid out like four 32-pixel tiles of the <2,2,2,1> epilogue: accumulator register
     // r holds quad row (r&3) + 8*(r>>2) + 4*kh, i.e. row quad r >> 3; output row 4*quad + o is tile row pair
     // 2*quad + (o >> 1), second row of the pair when o is odd -> tile-row index i = 2*(r>>3) + (o>>1), r' = (r&7) + 8*(o&1)
-    conv_epilogue_with<2, 2, 2, 1>(a, smem, m_tl, n0, M, HW, (int)blockIdx.y, W, [&](float* Cs, int CROW) {
+    auto scatter = [&](float* Cs, int CROW) {
         float* Cw = Cs + wn * 32 + li;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -1621,15 +1742,27 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
             }
             if (pass == 0) __syncthreads();
         }
-    });
+    };
+    if constexpr (SPLIT) {                               // split slices: raw partial tiles through the shared epilogue
+        conv_epilogue_with<2, 2, 2, 1>(a, smem, m_tl, n0, M, HW, (int)blockIdx.y, W, scatter);
+    } else {
+        constexpr int CROW = 68;
+        scatter(smem, CROW);
+        __syncthreads();
+        const int bsmp = m_tl / HW;
+        const int rem = m_tl - bsmp * HW;
+        tile128x64_out<float>(a, smem, CROW, smem + 128 * CROW, m_tl, W, n0, bsmp,
+                              ((rem / W) >> 3) * (W >> 4) + ((rem % W) >> 4));
+    }
 }
 
-template <int GN>
+// SPLIT: the launch is sliced over chunks (gridDim.y > 1) and every block leaves a raw partial tile
+template <int GN, bool SPLIT = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_f43_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // waves 0,1: component half 0; waves 2,3: half 1.  Both bodies execute the same barriers.
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7)) conv3x3_f43_body<GN, 1>(a, smem);
-    else conv3x3_f43_body<GN, 0>(a, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7)) conv3x3_f43_body<GN, 1, SPLIT>(a, smem);
+    else conv3x3_f43_body<GN, 0, SPLIT>(a, smem);
 }
 
 // [Cout][9][Cin] -> fragment order [Cout/32][kx][Cin/32][component 0..5][k-block j][lane][4]; stored component order:
@@ -1672,16 +1805,19 @@ static int launch_f43(const ConvArgs& a, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int grid = (int)(M / 128) * (a.Cout / 64);
     const int ks = a.ksplit > 1 ? a.ksplit : 1;       // slices of 32-channel chunks (gridDim.y), see wino_plan
-    const size_t lds = 2 * 10 * F43_HROW * sizeof(float);              // two halo buffers; > the epilogue's 43 KB
-    if (const int rc = allow_lds<&conv3x3_f43_kernel<0>>(lds)) return rc;
-    if (const int rc = allow_lds<&conv3x3_f43_kernel<1>>(lds)) return rc;
-    if (const int rc = allow_lds<&conv3x3_f43_kernel<2>>(lds)) return rc;
-    if (a.gn.mean && a.gn_silu)
-        hipLaunchKernelGGL(conv3x3_f43_kernel<2>, dim3(grid, ks), dim3(256), lds, s, a);
-    else if (a.gn.mean)
-        hipLaunchKernelGGL(conv3x3_f43_kernel<1>, dim3(grid, ks), dim3(256), lds, s, a);
-    else
-        hipLaunchKernelGGL(conv3x3_f43_kernel<0>, dim3(grid, ks), dim3(256), lds, s, a);
+    const size_t lds = 2 * 10 * F43_HROW * sizeof(float);              // two halo buffers; > the epilogue's C tile
+    const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;
+#define FLOWSE_LF43(G, SP)                                                                                   \
+    {                                                                                                        \
+        if (const int rc = allow_lds<&conv3x3_f43_kernel<G, SP>>(lds)) return rc;                            \
+        hipLaunchKernelGGL((conv3x3_f43_kernel<G, SP>), dim3(grid, ks), dim3(256), lds, s, a);               \
+    }
+    if (a.partial) {
+        if (gn == 2) FLOWSE_LF43(2, true) else if (gn == 1) FLOWSE_LF43(1, true) else FLOWSE_LF43(0, true)
+    } else {
+        if (gn == 2) FLOWSE_LF43(2, false) else if (gn == 1) FLOWSE_LF43(1, false) else FLOWSE_LF43(0, false)
+    }
+#undef FLOWSE_LF43
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }
@@ -1911,6 +2047,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
         const int buf = s & 1;                                                                                       \
         gloadB(min(s + 2, S_all - 1), RL);                                                                           \
         if (tap == 7) gloadH(min(chunk + 1, nchunks - 1));                                                           \
+        __builtin_amdgcn_sched_barrier(0); /* requests go out before the MFMAs (hipcc sinks them otherwise) */      \
         if (tap == 8) xformH();                                                                                      \
         constexpr int tapoff = ((tap / 3 - 1) * 18 + (tap % 3 - 1)) * ROWB;                                          \
         const char* Bb = Bs + buf * BN * ROWB + (wn * 64 + li) * ROWB + kh * 16;                                     \
@@ -1964,6 +2101,286 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
     }
 #undef FLOWSE_STEP16
     conv_epilogue<2, 2, 2, 2, OT>(a, acc, smem, m_tl, n0, M, HW, 0, W);
+}
+
+// raw (un-widened) channel quad: 4 dwords for float, 2 for the 16-bit types
+template <class ST> struct RawQuad { typedef u32x4 type; };
+template <> struct RawQuad<bf16_t> { typedef unsigned int type __attribute__((ext_vector_type(2))); };
+template <> struct RawQuad<f16_t> { typedef unsigned int type __attribute__((ext_vector_type(2))); };
+template <class ST>
+__device__ __forceinline__ typename RawQuad<ST>::type buf_ld_raw(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (std::is_same<ST, float>::value) return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    else return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+}
+template <class ST>
+__device__ __forceinline__ u32x4 widen_quad(typename RawQuad<ST>::type t) {
+    if constexpr (std::is_same<ST, float>::value) {
+        return t;
+    } else if constexpr (std::is_same<ST, bf16_t>::value) {
+        u32x4 o;
+        o.x = t.x << 16; o.y = t.x & 0xffff0000u; o.z = t.y << 16; o.w = t.y & 0xffff0000u;
+        return o;
+    } else {
+        const _Float16 e0 = __builtin_bit_cast(_Float16, (unsigned short)(t.x & 0xffffu));
+        const _Float16 e1 = __builtin_bit_cast(_Float16, (unsigned short)(t.x >> 16));
+        const _Float16 e2 = __builtin_bit_cast(_Float16, (unsigned short)(t.y & 0xffffu));
+        const _Float16 e3 = __builtin_bit_cast(_Float16, (unsigned short)(t.y >> 16));
+        u32x4 o;
+        o.x = __float_as_uint((float)e0); o.y = __float_as_uint((float)e1);
+        o.z = __float_as_uint((float)e2); o.w = __float_as_uint((float)e3);
+        return o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Single-plane (bf16 / half) LDS-halo 3x3 kernel, built for THREE blocks per CU.
+//
+// Same tile (8 x 16 pixels x 128 output channels, 4 waves x 2 x 2 tiles of v_mfma_f32_32x32x16) and the same halo staging
+// with fused GroupNorm + SiLU as conv3x3_halo_bf16_kernel.  A 16-bit MFMA phase is 16x shorter than an fp32 one, so with
+// K = 9 x 128 .. 9 x 512 the kernel is a chain of short latencies -- LDS fragment reads, one barrier per tap, the
+// epilogue (which for K = 1152 costs about as many issue cycles as the whole main loop) -- and what hides them is
+// occupancy: measured (rocprofv3 SQ counters) the two-blocks-per-CU form kept the matrix pipe 28 % busy with the waves
+// parked on s_waitcnt / s_barrier 36 % of the time, no matter whether one or three taps were staged per barrier.  So:
+//   * LDS <= 43 KB: one tap's weight tile (10 KB) double-buffered + the halo (15 KB); the epilogue handles the 128
+//     output channels as two halves of 64 through a 35 KB C tile;
+//   * <= 168 VGPRs: one weight register set, requested one tap ahead (pinned in front of the MFMAs: hipcc otherwise
+//     sinks the loads behind them and exposes the full L2 latency every tap).
+// IT / OT: storage types of the inputs and of res / out (float, or the 16-bit type of the operands).
+template <bool GN, bool F16, class IT, class OT>
+__global__ __launch_bounds__(256, 3) void conv3x3_halo16_kernel(ConvArgs a) {
+    constexpr int BN = 128, ROWB = 80, HROWS = 180, H_LOADS = 6;
+    constexpr int HPITCH = 18 * ROWB + 96;                 // halo image row: 1536 B = 0 mod 256, so the two image rows a
+                                                           // wave's 32 lanes touch use the same bank pattern (conflict-free)
+    constexpr int BTILE = BN * ROWB;                       // one tap's weight tile
+    constexpr unsigned ES = sizeof(IT);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Hs = reinterpret_cast<char*>(smem);              // [10][HPITCH]
+    char* Bs = Hs + 10 * HPITCH;                           // [2 buffers][BN][ROWB]
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int M = a.B * HW;
+    const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
+    const int nchunks = Cin / KC;
+    const int n_ntiles = a.Cout / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
+    const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 3);
+    const int b = mt / tiles_img, tt = mt - b * tiles_img;
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int y0 = ty * 8, x0 = tx * 16, n0 = nt * BN;
+    const int m_tl = (b * H + y0) * W + x0;
+
+    const int col4 = tid & 7, row0 = tid >> 3;             // halo staging: 8 channel quads x 32 rows per pass
+    unsigned hpix[H_LOADS];                                // pixel offset of this thread's halo quads inside the window
+    int hlds[H_LOADS];                                     // their LDS byte offset (-1: past the last halo pixel)
+    unsigned hin = 0;                                      // bit q: quad q lies inside the image
+#pragma unroll
+    for (int q = 0; q < H_LOADS; ++q) {
+        const int hr = row0 + 32 * q;
+        const int hy = hr / 18, hx = hr - hy * 18;
+        const bool in = hr < HROWS && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+        hpix[q] = (unsigned)(hy * W + hx);
+        hlds[q] = hr < HROWS ? hy * HPITCH + hx * ROWB + col4 * 8 : -1;
+        hin |= in ? (1u << q) : 0u;
+    }
+    const int bcol = tid & 3, brow0 = tid >> 2;            // weight staging: 4 x 16-byte columns, rows brow0 + 64 q
+    const unsigned bvo0 = (unsigned)((n0 + brow0) * 9 * nchunks * 64 + bcol * 16), bvo_step = (unsigned)(64 * 9 * nchunks * 64);
+    const int64_t wbase = (int64_t)m_tl - W - 1;
+    const int wpix = 9 * W + 18;
+    const IT* in1p = reinterpret_cast<const IT*>(a.in1);
+    const IT* in2p = reinterpret_cast<const IT*>(a.in2);
+    const __amdgpu_buffer_rsrc_t rsrc1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<IT*>(in1p + wbase * C1), 0, wpix * C1 * (int)ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<IT*>(C2 ? in2p + wbase * C2 : in1p), 0, C2 ? wpix * C2 * (int)ES : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wq), 0, a.Cout * 9 * nchunks * 64, 0x00020000);
+
+    typename RawQuad<IT>::type rh[H_LOADS];                // raw until transformed; afterwards .xy = the quad as 4 x 16 bit
+    u32x4 rb[2];
+    float4 g_mu, g_sc, g_be;
+    auto gloadH = [&](int chunk) {
+        const int c0 = chunk * KC;
+        const bool second = c0 >= C1;
+        const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * ES;
+        const unsigned cs = (unsigned)(second ? C2 : C1);
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            const unsigned off = ((hin >> q) & 1u) ? (hpix[q] * cs + (unsigned)col4 * 4u) * ES : OOB;
+            rh[q] = second ? buf_ld_raw<IT>(rsrc2, off, soff) : buf_ld_raw<IT>(rsrc1, off, soff);
+        }
+        if (GN) {
+            const int cg = c0 + col4 * 4;
+            g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
+            g_sc = *reinterpret_cast<const float4*>(a.gn.scale + (int64_t)b * Cin + cg);
+            g_be = *reinterpret_cast<const float4*>(a.gn.beta + cg);
+        }
+    };
+    // GroupNorm + SiLU of quad Q in fp32 (packed forms, v_exp / v_rcp), then one rounding to the operand type:
+    // rh[Q].xy = the quad as 4 x 16 bit.  Out-of-image pixels are zero AFTER the activation.
+    auto xform1 = [&](int Q) {
+        u32x4 t = widen_quad<IT>(rh[Q]);
+        if (GN) t = a.gn_silu ? gn_quad<2>(t, g_mu, g_sc, g_be, (hin >> Q) & 1u) : gn_quad<1>(t, g_mu, g_sc, g_be, (hin >> Q) & 1u);
+        const float v[4] = {__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+        unsigned short h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (F16) {
+                const _Float16 c = (_Float16)v[e];
+                h[e] = __builtin_bit_cast(unsigned short, c);
+            } else {
+                const __bf16 c = (__bf16)v[e];
+                h[e] = __builtin_bit_cast(unsigned short, c);
+            }
+        }
+        rh[Q].x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+        rh[Q].y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+    };
+    auto lstoreH = [&]() {
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q)
+            if (hlds[q] >= 0) *reinterpret_cast<uint2*>(Hs + hlds[q]) = make_uint2(rh[q].x, rh[q].y);
+    };
+    const int S_all = nchunks * 9;
+    auto gloadB = [&](int s) {
+        const int chunk = s / 9, tap = s - chunk * 9;
+        const unsigned soff_b = (unsigned)((tap * nchunks + chunk) * 64);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo0 + q * bvo_step, soff_b, 0);
+    };
+    auto lstoreB = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            *reinterpret_cast<u32x4*>(Bs + buf * BTILE + (brow0 + 64 * q) * ROWB + bcol * 16) = rb[q];
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, kh = lane >> 5;
+    int abase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int py = 2 * (wm * 2 + i) + (li >> 4), px = li & 15;
+        abase[i] = (py + 1) * HPITCH + (px + 1) * ROWB + kh * 16;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gloadH(0);
+    gloadB(0);
+#pragma unroll
+    for (int q = 0; q < H_LOADS; ++q) xform1(q);
+    lstoreH();
+    lstoreB(0);
+    __syncthreads();
+
+    // One tap.  TAP is a literal: the nine taps of a chunk are straight-line code, no load sits under a branch.  The
+    // next tap's weights are requested first (pinned in front of the MFMAs), the next chunk's halo at tap 1; its six
+    // quads are normalised one per tap behind the MFMAs of taps 2..7 and written after tap 8's barrier.
+#define FLOWSE_TAP16(TAP)                                                                                            \
+    {                                                                                                                \
+        constexpr int tap = TAP;                                                                                     \
+        const int s = chunk * 9 + tap;                                                                               \
+        const int buf = s & 1;                                                                                       \
+        if (!(a.dbg & 1)) gloadB(min(s + 1, S_all - 1));                                                             \
+        if (tap == 1 && !(a.dbg & 2)) gloadH(min(chunk + 1, nchunks - 1));                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        constexpr int tapoff = (tap / 3 - 1) * HPITCH + (tap % 3 - 1) * ROWB;                                        \
+        const char* Bb = Bs + buf * BTILE + (wn * 64 + li) * ROWB + kh * 16;                                         \
+        if (!(a.dbg & 4)) _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) {                                         \
+            bf16x8 af[2], bf[2];                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+                af[i] = *reinterpret_cast<const bf16x8*>(Hs + abase[i] + tapoff + mh * 32);                          \
+                bf[i] = *reinterpret_cast<const bf16x8*>(Bb + i * 32 * ROWB + mh * 32);                              \
+            }                                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) {            \
+                if (F16)                                                                                             \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]),             \
+                                                                      __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0); \
+                else                                                                                                 \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);           \
+            }                                                                                                        \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if (tap >= 2 && tap <= 7 && !(a.dbg & 2)) xform1(tap - 2); /* VALU in the shadow of the MFMAs just issued */ \
+        if (!(a.dbg & 1)) lstoreB(buf ^ 1);              /* at the very last tap: a spare tile into the idle buffer */ \
+        if (!(a.dbg & 16)) __syncthreads();                                                                                             \
+        if (tap == 8 && !(a.dbg & 2)) {                  /* everyone is done with this chunk's halo */              \
+            lstoreH();                                                                                               \
+            __syncthreads();                                                                                         \
+        }                                                                                                            \
+    }
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        FLOWSE_TAP16(0) FLOWSE_TAP16(1) FLOWSE_TAP16(2) FLOWSE_TAP16(3) FLOWSE_TAP16(4)
+        FLOWSE_TAP16(5) FLOWSE_TAP16(6) FLOWSE_TAP16(7) FLOWSE_TAP16(8)
+    }
+#undef FLOWSE_TAP16
+
+    if (a.dbg & 8) return;                                 // ablation: no epilogue
+    // ---- epilogue in two halves of 64 output channels (C tile [128][68] floats = 35 KB instead of 68 KB).  Half h is
+    // held by the waves with wn == h; then all 256 threads run the shared output stage on it.
+    {
+        constexpr int CROW = 68;
+        float* Cs = smem;
+        float* red = smem + 128 * CROW;
+        const int bsmp = m_tl / HW;
+        const int rem = m_tl - bsmp * HW;
+        const int tile = ((rem / W) >> 3) * (W >> 4) + ((rem % W) >> 4);
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();                               // previous users of the tile (main loop / first half) are done
+            if (wn == half) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                            Cs[row * CROW + jn * 32 + li] = acc[i][jn][r];
+                        }
+            }
+            __syncthreads();
+            tile128x64_out<OT>(a, Cs, CROW, red, m_tl, W, n0 + half * 64, bsmp, tile);
+        }
+    }
+}
+
+template <bool F16>
+static int launch_halo16(const ConvArgs& a_in, hipStream_t s) {
+    using T16 = typename std::conditional<F16, f16_t, bf16_t>::type;
+    const ConvArgs& a0 = a_in;
+    const int64_t M = (int64_t)a0.B * a0.H * a0.W;
+    const int grid = (int)(M / 128) * (a0.Cout / 128);
+    const size_t lds_stage = (size_t)10 * (18 * 80 + 96) + (size_t)2 * 128 * 80;
+    const size_t lds_epi = ((size_t)128 * 68 + 4 * 64 * 2) * sizeof(float);
+    const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    if (a0.in_dt != a0.out_dt || (a0.in_dt != DT_F32 && a0.in_dt != St<T16>::dt) || a0.terms != 1 || a0.partial) {
+        set_error("halo16: input / output storage must agree and match the operand type; no split-K form");
+        return ERR_ARG;
+    }
+    static const int abl = getenv("FLOWSE_ABL16") ? atoi(getenv("FLOWSE_ABL16")) : 0;
+    ConvArgs a = a_in;
+    a.dbg = abl;
+#define FLOWSE_LH16(GNF, IT, OT)                                                                                  \
+    {                                                                                                             \
+        if (const int rc = allow_lds<&conv3x3_halo16_kernel<GNF, F16, IT, OT>>(lds)) return rc;                   \
+        hipLaunchKernelGGL((conv3x3_halo16_kernel<GNF, F16, IT, OT>), dim3(grid), dim3(256), lds, s, a);          \
+    }
+    if (a.in_dt == DT_F32) {
+        if (a.gn.mean) FLOWSE_LH16(true, float, float) else FLOWSE_LH16(false, float, float)
+    } else {
+        if (a.gn.mean) FLOWSE_LH16(true, T16, T16) else FLOWSE_LH16(false, T16, T16)
+    }
+#undef FLOWSE_LH16
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2329,8 +2746,12 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
             conv_supports_head4(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))
             return launch_head4(a, s);
         if (a.ksplit <= 1 && a.out_dt == a.in_dt && conv16_uses_halo(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
-            if (a.wq_f16) return launch_halo_bf16<1, true>(a, s);
-            return launch_halo_bf16<1>(a, s);
+            // the three-blocks-per-CU kernel wins once there are >= 1024 blocks (>= 4 / 3 rounds of 768); smaller grids
+            // keep the two-blocks-per-CU form (FLOWSE_HALO16_PER_TAP=1 forces it everywhere: A-B hook)
+            static const bool per_tap = getenv("FLOWSE_HALO16_PER_TAP") != nullptr;
+            const int64_t blocks = ((int64_t)a.B * a.H * a.W / 128) * (a.Cout / 128);
+            if (per_tap || blocks < 1024) return a.wq_f16 ? launch_halo_bf16<1, true>(a, s) : launch_halo_bf16<1>(a, s);
+            return a.wq_f16 ? launch_halo16<true>(a, s) : launch_halo16<false>(a, s);
         }
         if (a.ksplit > 1 && !a.partial) {
             set_error("conv: split-K needs a partial buffer");
@@ -2345,8 +2766,11 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
     if (a.ksplit <= 1 && conv_supports_fused_gn(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
         if (a.wq && (a.Cout % 128) == 0) {
             if (a.terms == 3 && !a.wq_f16) return launch_halo_bf16<3>(a, s);
-            if (a.terms == 1 && !a.wq_f16) return launch_halo_bf16<1>(a, s);
-            if (a.terms == 1 && a.wq_f16) return launch_halo_bf16<1, true>(a, s);
+            if (a.terms == 1) {
+                const int64_t blocks = ((int64_t)a.B * a.H * a.W / 128) * (a.Cout / 128);
+                if (blocks < 1024) return a.wq_f16 ? launch_halo_bf16<1, true>(a, s) : launch_halo_bf16<1>(a, s);
+                return a.wq_f16 ? launch_halo16<true>(a, s) : launch_halo16<false>(a, s);
+            }
             set_error("conv: 16-bit path needs terms = 1 (bf16 / f16) or 3 (bf16 only)");
             return ERR_ARG;
         }
