@@ -245,7 +245,6 @@ struct ConvArgs {
     // and by the 4-channel heads; 16-bit outputs by those plus the 4-channel input convs, the fp32 flat kernel
     // (attention output projection) and the split-K reductions.
     int in_dt = DT_F32, out_dt = DT_F32;
-    int dbg = 0;        // timing ablations of the 16-bit halo kernel (FLOWSE_ABL16 bit mask; results are wrong when set)
 };
 // K slices of the 16-bit flat kernel for a shape (its own policy: no Winograd alternative, two K steps per stage)
 int conv16_ksplit(int B, int H, int W, int Cin, int Cout, int taps);

@@ -2288,12 +2288,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo16_kernel(ConvArgs a) {
         constexpr int tap = TAP;                                                                                     \
         const int s = chunk * 9 + tap;                                                                               \
         const int buf = s & 1;                                                                                       \
-        if (!(a.dbg & 1)) gloadB(min(s + 1, S_all - 1));                                                             \
-        if (tap == 1 && !(a.dbg & 2)) gloadH(min(chunk + 1, nchunks - 1));                                           \
+        gloadB(min(s + 1, S_all - 1));                                                                               \
+        if (tap == 1) gloadH(min(chunk + 1, nchunks - 1));                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         constexpr int tapoff = (tap / 3 - 1) * HPITCH + (tap % 3 - 1) * ROWB;                                        \
         const char* Bb = Bs + buf * BTILE + (wn * 64 + li) * ROWB + kh * 16;                                         \
-        if (!(a.dbg & 4)) _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) {                                         \
+        _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) {                                                           \
             bf16x8 af[2], bf[2];                                                                                     \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
                 af[i] = *reinterpret_cast<const bf16x8*>(Hs + abase[i] + tapoff + mh * 32);                          \
@@ -2308,10 +2308,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo16_kernel(ConvArgs a) {
             }                                                                                                        \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if (tap >= 2 && tap <= 7 && !(a.dbg & 2)) xform1(tap - 2); /* VALU in the shadow of the MFMAs just issued */ \
-        if (!(a.dbg & 1)) lstoreB(buf ^ 1);              /* at the very last tap: a spare tile into the idle buffer */ \
-        if (!(a.dbg & 16)) __syncthreads();                                                                                             \
-        if (tap == 8 && !(a.dbg & 2)) {                  /* everyone is done with this chunk's halo */              \
+        if (tap >= 2 && tap <= 7) xform1(tap - 2);       /* VALU in the shadow of the MFMAs just issued */           \
+        lstoreB(buf ^ 1);                                /* at the very last tap: a spare tile into the idle buffer */ \
+        __syncthreads();                                                                                             \
+        if (tap == 8) {                                  /* everyone is done with this chunk's halo */              \
             lstoreH();                                                                                               \
             __syncthreads();                                                                                         \
         }                                                                                                            \
@@ -2322,7 +2322,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo16_kernel(ConvArgs a) {
     }
 #undef FLOWSE_TAP16
 
-    if (a.dbg & 8) return;                                 // ablation: no epilogue
     // ---- epilogue in two halves of 64 output channels (C tile [128][68] floats = 35 KB instead of 68 KB).  Half h is
     // held by the waves with wn == h; then all 256 threads run the shared output stage on it.
     {
@@ -2365,9 +2364,7 @@ static int launch_halo16(const ConvArgs& a_in, hipStream_t s) {
         set_error("halo16: input / output storage must agree and match the operand type; no split-K form");
         return ERR_ARG;
     }
-    static const int abl = getenv("FLOWSE_ABL16") ? atoi(getenv("FLOWSE_ABL16")) : 0;
-    ConvArgs a = a_in;
-    a.dbg = abl;
+    const ConvArgs& a = a_in;
 #define FLOWSE_LH16(GNF, IT, OT)                                                                                  \
     {                                                                                                             \
         if (const int rc = allow_lds<&conv3x3_halo16_kernel<GNF, F16, IT, OT>>(lds)) return rc;                   \
