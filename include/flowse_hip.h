@@ -99,15 +99,21 @@ int flowse_model_param_info(const flowse_model* m, int index, char* name, int na
  * one stacked Dense_0 matrix) on the current HIP device. */
 int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel);
 
-/* Matrix-core operand precision of the large 3x3 ResBlock convolutions (call BEFORE flowse_model_load_weights; a
- * change drops the uploaded weights).  0 (default): every operand, product and accumulation is fp32
- * (v_mfma_f32_32x32x2_f32).  3x3 convolutions with Cin % 32 == 0 and Cout % 64 == 0 on images the LDS-halo kernel
- * covers are evaluated in the F(4,3) Winograd form along the filter's vertical axis (half the multiplies; transformed
- * fp32 operands, rounding error ~3x the direct sum's, 4e-7..2e-6 rel-L2 per layer); FLOWSE_WINOGRAD=f23 selects the
- * F(2,3) form, FLOWSE_NO_WINOGRAD=1 the direct form, whose result is bit for bit an fmaf chain.  1 "bf16x3": operands split
- * x = hi + lo in bf16, products hi*hi + hi*lo + lo*hi accumulated in fp32 (fp32-class accuracy, ~1e-5).  2 "bf16":
- * plain bf16 operands (BASELINE config 3).  3 "fp16": IEEE half operands (BASELINE config 5).  Accumulation,
- * GroupNorm statistics, residuals and activations stay fp32 in every mode. */
+/* Precision mode (call BEFORE flowse_model_load_weights; a change drops the uploaded weights).
+ * 0 (default): every operand, product and accumulation is fp32 (v_mfma_f32_32x32x2_f32), activations fp32.  3x3
+ *   convolutions with Cin % 32 == 0 and Cout % 64 == 0 on images the LDS-halo kernel covers are evaluated in the F(4,3)
+ *   Winograd form along the filter's vertical axis (half the multiplies; transformed fp32 operands, rounding error ~3x
+ *   the direct sum's, 4e-7..2e-6 rel-L2 per layer); FLOWSE_WINOGRAD=f23 selects the F(2,3) form, FLOWSE_NO_WINOGRAD=1
+ *   the direct form, whose result is bit for bit an fmaf chain.
+ * 1 "bf16x3": fp32 activations; the operands of the big 3x3 convs are split x = hi + lo in bf16 and the products
+ *   hi*hi + hi*lo + lo*hi accumulated in fp32 (fp32-class accuracy, ~1e-5 end to end).
+ * 2 "bf16" (BASELINE config 3) / 3 "fp16" (BASELINE config 5): 16-bit STORAGE modes -- every wide activation tensor
+ *   between kernels is bf16 / IEEE half, all matrix products run on the 16-bit matrix cores (a 16-bit twin of the packed
+ *   weights is kept), accumulators, GroupNorm statistics, time-embedding tables, split-K slabs, the 4-channel pyramid
+ *   tensors and the interior of the attention blocks stay fp32.  Applies to networks whose wide channel counts are
+ *   multiples of 32 (the released configuration); otherwise storage stays fp32 and only the operands of the 3x3 convs
+ *   with Cout % 128 == 0 become 16-bit.  FLOWSE_FP32_STORAGE=1 forces that operand-only form.
+ * The boundary tensors (x, y, out: complex64; t: float32) are the same in every mode. */
 int flowse_model_set_precision(flowse_model* m, int mode);
 
 /* Optional: plan buffers for a shape ahead of time (otherwise done lazily by the first call).

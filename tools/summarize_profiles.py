@@ -42,6 +42,17 @@ def main(tag):
             if float(r["Percentage"]) >= 0.005:
                 w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                             r["MinNs"], r["MaxNs"]])
+    for sub, name in (("prof_bf16", "bf16"), ("prof_cfg5", "config5_rk4_fp16")):     # other modes: --stats summaries only
+        src = os.path.join(G, sub, f"{tag}_kernel_stats.csv")
+        if os.path.exists(src):
+            with open(os.path.join(P, f"{tag}_{name}_kernel_stats.csv"), "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+                for r in csv.DictReader(open(src)):
+                    if float(r["Percentage"]) >= 0.005:
+                        w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                                    r["MinNs"], r["MaxNs"]])
+            print("wrote", os.path.join(P, f"{tag}_{name}_kernel_stats.csv"))
     fetch = agg(os.path.join(G, "prof_fetch", f"{tag}_counter_collection.csv"), "FETCH_SIZE")
     write = agg(os.path.join(G, "prof_write", f"{tag}_counter_collection.csv"), "WRITE_SIZE")
     out = {}
@@ -53,7 +64,8 @@ def main(tag):
         out[k[:120]] = {"launches": n, "FETCH_SIZE_KB_per_launch_raw": fs / n,
                         "WRITE_SIZE_KB_per_launch": ws / n,
                         "hbm_bytes_per_launch": (2.0 * fs + ws) * 1024.0 / n}
-    dom = ([k for k in out if "conv3x3_f43_kernel<2>" in k] or [k for k in out if "conv3x3_wino_kernel<2>" in k] or
+    dom = ([k for k in out if "conv3x3_f43_kernel<2, false>" in k] or [k for k in out if "conv3x3_f43_kernel<2>" in k] or
+           [k for k in out if "conv3x3_wino_kernel<2>" in k] or
            [k for k in out if "conv3x3_halo_kernel<2, 2, 2, 2, 2>" in k])
     summary = {"unit_note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving correction)",
                "dominant_kernel": dom[0] if dom else None, "kernels": out}
