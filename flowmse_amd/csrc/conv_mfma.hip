@@ -2146,16 +2146,20 @@ __device__ __forceinline__ u32x4 widen_quad(typename RawQuad<ST>::type t) {
 //   * <= 168 VGPRs: one weight register set, requested one tap ahead (pinned in front of the MFMAs: hipcc otherwise
 //     sinks the loads behind them and exposes the full L2 latency every tap).
 // IT / OT: storage types of the inputs and of res / out (float, or the 16-bit type of the operands).
-template <bool GN, bool F16, class IT, class OT>
-__global__ __launch_bounds__(256, 3) void conv3x3_halo16_kernel(ConvArgs a) {
-    constexpr int BN = 128, ROWB = 80, HROWS = 180, H_LOADS = 6;
+// MT = 8 x 16 pixel sub-tiles per block, stacked vertically: 1 (three blocks per CU) or 2 (a 16 x 16 pixel tile, two
+// blocks per CU, 16-bit inputs only).  With MT = 2 every staged weight tile feeds twice the MFMAs: half the per-block
+// weight stream from L2, half the barriers and B-fragment reads per MFMA, a smaller halo overhead (324 / 256 vs 180 / 128
+// pixels read per pixel computed).
+template <bool GN, bool F16, class IT, class OT, int MT = 1>
+__global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(ConvArgs a) {
+    constexpr int BN = 128, ROWB = 80, TROWS = 8 * MT, HROWS = (TROWS + 2) * 18, H_LOADS = (HROWS * 8 + 255) / 256;
     constexpr int HPITCH = 18 * ROWB + 96;                 // halo image row: 1536 B = 0 mod 256, so the two image rows a
                                                            // wave's 32 lanes touch use the same bank pattern (conflict-free)
     constexpr int BTILE = BN * ROWB;                       // one tap's weight tile
     constexpr unsigned ES = sizeof(IT);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* Hs = reinterpret_cast<char*>(smem);              // [10][HPITCH]
-    char* Bs = Hs + 10 * HPITCH;                           // [2 buffers][BN][ROWB]
+    char* Hs = reinterpret_cast<char*>(smem);              // [TROWS + 2][HPITCH]
+    char* Bs = Hs + (TROWS + 2) * HPITCH;                           // [2 buffers][BN][ROWB]
 
     const int tid = threadIdx.x;
     const int H = a.H, W = a.W, HW = H * W;
@@ -2165,10 +2169,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo16_kernel(ConvArgs a) {
     const int n_ntiles = a.Cout / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
-    const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 3);
+    const int tiles_x = W >> 4, tiles_img = tiles_x * (H / TROWS);
     const int b = mt / tiles_img, tt = mt - b * tiles_img;
     const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
-    const int y0 = ty * 8, x0 = tx * 16, n0 = nt * BN;
+    const int y0 = ty * TROWS, x0 = tx * 16, n0 = nt * BN;
     const int m_tl = (b * H + y0) * W + x0;
 
     const int col4 = tid & 7, row0 = tid >> 3;             // halo staging: 8 channel quads x 32 rows per pass
@@ -2187,7 +2191,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo16_kernel(ConvArgs a) {
     const int bcol = tid & 3, brow0 = tid >> 2;            // weight staging: 4 x 16-byte columns, rows brow0 + 64 q
     const unsigned bvo0 = (unsigned)((n0 + brow0) * 9 * nchunks * 64 + bcol * 16), bvo_step = (unsigned)(64 * 9 * nchunks * 64);
     const int64_t wbase = (int64_t)m_tl - W - 1;
-    const int wpix = 9 * W + 18;
+    const int wpix = (TROWS + 1) * W + 18;
     const IT* in1p = reinterpret_cast<const IT*>(a.in1);
     const IT* in2p = reinterpret_cast<const IT*>(a.in2);
     const __amdgpu_buffer_rsrc_t rsrc1 =
@@ -2258,19 +2262,21 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo16_kernel(ConvArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, kh = lane >> 5;
-    int abase[2];
+    int abase[2];                                          // sub-tile 0; sub-tile t adds 8 t image rows
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int py = 2 * (wm * 2 + i) + (li >> 4), px = li & 15;
         abase[i] = (py + 1) * HPITCH + (px + 1) * ROWB + kh * 16;
     }
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
 
     gloadH(0);
     gloadB(0);
@@ -2294,21 +2300,28 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo16_kernel(ConvArgs a) {
         constexpr int tapoff = (tap / 3 - 1) * HPITCH + (tap % 3 - 1) * ROWB;                                        \
         const char* Bb = Bs + buf * BTILE + (wn * 64 + li) * ROWB + kh * 16;                                         \
         _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) {                                                           \
-            bf16x8 af[2], bf[2];                                                                                     \
+            bf16x8 af[MT][2], bf[2];                                                                                 \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
-                af[i] = *reinterpret_cast<const bf16x8*>(Hs + abase[i] + tapoff + mh * 32);                          \
+                _Pragma("unroll") for (int t = 0; t < MT; ++t)                                                       \
+                    af[t][i] = *reinterpret_cast<const bf16x8*>(Hs + abase[i] + t * 8 * HPITCH + tapoff + mh * 32);  \
                 bf[i] = *reinterpret_cast<const bf16x8*>(Bb + i * 32 * ROWB + mh * 32);                              \
             }                                                                                                        \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) {            \
+            _Pragma("unroll") for (int t = 0; t < MT; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i)             \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
                 if (F16)                                                                                             \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]),             \
-                                                                      __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0); \
+                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[t][i]),       \
+                                                                         __builtin_bit_cast(f16x8, bf[j]), acc[t][i][j], 0, 0, 0); \
                 else                                                                                                 \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);           \
+                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][i], bf[j], acc[t][i][j], 0, 0, 0);  \
             }                                                                                                        \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if (tap >= 2 && tap <= 7) xform1(tap - 2);       /* VALU in the shadow of the MFMAs just issued */           \
+        /* GroupNorm of the next chunk's quads, in the shadow of the MFMAs just issued: taps 2..7 take them all */   \
+        if (tap >= 2 && tap <= 7) {                                                                                  \
+            constexpr int QPT = (H_LOADS + 5) / 6;                                                                   \
+            _Pragma("unroll") for (int qq = 0; qq < QPT; ++qq)                                                       \
+                if ((tap - 2) * QPT + qq < H_LOADS) xform1((tap - 2) * QPT + qq);                                    \
+        }                                                                                                            \
         lstoreB(buf ^ 1);                                /* at the very last tap: a spare tile into the idle buffer */ \
         __syncthreads();                                                                                             \
         if (tap == 8) {                                  /* everyone is done with this chunk's halo */              \
@@ -2330,50 +2343,56 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo16_kernel(ConvArgs a) {
         float* red = smem + 128 * CROW;
         const int bsmp = m_tl / HW;
         const int rem = m_tl - bsmp * HW;
-        const int tile = ((rem / W) >> 3) * (W >> 4) + ((rem % W) >> 4);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int tile = (((rem / W) >> 3) + t) * (W >> 4) + ((rem % W) >> 4);     // 8 x 16 statistics tiles, row-major
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            __syncthreads();                               // previous users of the tile (main loop / first half) are done
-            if (wn == half) {
+            for (int half = 0; half < 2; ++half) {
+                __syncthreads();                           // previous users of the tile (main loop / earlier pass) are done
+                if (wn == half) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int jn = 0; jn < 2; ++jn)
+                        for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                            Cs[row * CROW + jn * 32 + li] = acc[i][jn][r];
-                        }
+                            for (int r = 0; r < 16; ++r) {
+                                const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                                Cs[row * CROW + jn * 32 + li] = acc[t][i][jn][r];
+                            }
+                }
+                __syncthreads();
+                tile128x64_out<OT>(a, Cs, CROW, red, m_tl + t * 8 * W, W, n0 + half * 64, bsmp, tile);
             }
-            __syncthreads();
-            tile128x64_out<OT>(a, Cs, CROW, red, m_tl, W, n0 + half * 64, bsmp, tile);
         }
     }
 }
 
 template <bool F16>
-static int launch_halo16(const ConvArgs& a_in, hipStream_t s) {
+static int launch_halo16(const ConvArgs& a, hipStream_t s) {
     using T16 = typename std::conditional<F16, f16_t, bf16_t>::type;
-    const ConvArgs& a0 = a_in;
-    const int64_t M = (int64_t)a0.B * a0.H * a0.W;
-    const int grid = (int)(M / 128) * (a0.Cout / 128);
-    const size_t lds_stage = (size_t)10 * (18 * 80 + 96) + (size_t)2 * 128 * 80;
-    const size_t lds_epi = ((size_t)128 * 68 + 4 * 64 * 2) * sizeof(float);
-    const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    if (a0.in_dt != a0.out_dt || (a0.in_dt != DT_F32 && a0.in_dt != St<T16>::dt) || a0.terms != 1 || a0.partial) {
+    const int64_t M = (int64_t)a.B * a.H * a.W;
+    if (a.in_dt != a.out_dt || (a.in_dt != DT_F32 && a.in_dt != St<T16>::dt) || a.terms != 1 || a.partial) {
         set_error("halo16: input / output storage must agree and match the operand type; no split-K form");
         return ERR_ARG;
     }
-    const ConvArgs& a = a_in;
-#define FLOWSE_LH16(GNF, IT, OT)                                                                                  \
+    // 16 x 16 pixel tiles (two sub-tiles per block) when the input is 16-bit, H allows it and >= 512 blocks remain
+    static const bool no_mt2 = getenv("FLOWSE_HALO16_MT1") != nullptr;                 // A-B hook
+    const bool mt2 = !no_mt2 && a.in_dt != DT_F32 && (a.H & 15) == 0 && (M / 256) * (a.Cout / 128) >= 512;
+    const int grid = (int)(M / (mt2 ? 256 : 128)) * (a.Cout / 128);
+    const size_t lds_stage = (size_t)(mt2 ? 18 : 10) * (18 * 80 + 96) + (size_t)2 * 128 * 80;
+    const size_t lds_epi = ((size_t)128 * 68 + 4 * 64 * 2) * sizeof(float);
+    const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+#define FLOWSE_LH16(GNF, IT, OT, MTV)                                                                             \
     {                                                                                                             \
-        if (const int rc = allow_lds<&conv3x3_halo16_kernel<GNF, F16, IT, OT>>(lds)) return rc;                   \
-        hipLaunchKernelGGL((conv3x3_halo16_kernel<GNF, F16, IT, OT>), dim3(grid), dim3(256), lds, s, a);          \
+        if (const int rc = allow_lds<&conv3x3_halo16_kernel<GNF, F16, IT, OT, MTV>>(lds)) return rc;              \
+        hipLaunchKernelGGL((conv3x3_halo16_kernel<GNF, F16, IT, OT, MTV>), dim3(grid), dim3(256), lds, s, a);     \
     }
     if (a.in_dt == DT_F32) {
-        if (a.gn.mean) FLOWSE_LH16(true, float, float) else FLOWSE_LH16(false, float, float)
+        if (a.gn.mean) FLOWSE_LH16(true, float, float, 1) else FLOWSE_LH16(false, float, float, 1)
+    } else if (mt2) {
+        if (a.gn.mean) FLOWSE_LH16(true, T16, T16, 2) else FLOWSE_LH16(false, T16, T16, 2)
     } else {
-        if (a.gn.mean) FLOWSE_LH16(true, T16, T16) else FLOWSE_LH16(false, T16, T16)
+        if (a.gn.mean) FLOWSE_LH16(true, T16, T16, 1) else FLOWSE_LH16(false, T16, T16, 1)
     }
 #undef FLOWSE_LH16
     FLOWSE_LAUNCH_CHECK();
