@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflowse_hip.so")
 SOURCES = ["model.hip", "conv_mfma.hip", "norm.hip", "fir.hip", "attention.hip", "misc.hip", "spec.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function"] + os.environ.get("FLOWSE_BUILD_FLAGS", "").split()   # e.g. -DFLOWSE_TS (measurement builds)
 
 
 def _digest():

@@ -59,6 +59,10 @@ template <> struct St<bf16_t> {
         const __bf16 x = (__bf16)a, y = (__bf16)b;                             // round to nearest even
         return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
     }
+    static __device__ __forceinline__ void unpack2(unsigned w, float& a, float& b) {
+        a = __uint_as_float(w << 16);
+        b = __uint_as_float(w & 0xffff0000u);
+    }
     static __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
         *reinterpret_cast<uint2*>(p) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
     }
@@ -76,6 +80,14 @@ template <> struct St<bf16_t> {
 template <> struct St<f16_t> {
     static constexpr int dt = DT_F16;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        const _Float16 x = (_Float16)a, y = (_Float16)b;
+        return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+    }
+    static __device__ __forceinline__ void unpack2(unsigned w, float& a, float& b) {
+        a = (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
+        b = (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+    }
     static __device__ __forceinline__ float4 ld4(const f16_t* p) {
         const h4 r = *reinterpret_cast<const h4*>(p);
         return make_float4((float)r.x, (float)r.y, (float)r.z, (float)r.w);

@@ -323,6 +323,135 @@ __device__ __forceinline__ void tile128x64_out(const ConvArgs& a, const float* C
     }
 }
 
+// ---- output stage straight from the accumulators of a [MT x 128 pixels][128 channels] block tile held as 4 waves x
+// MT x 2 x 2 tiles of the 32x32 MFMA, 16-bit storage.  In the C/D layout a lane owns ONE output channel (col = lane & 31)
+// at 16 pixels of every tile, so the per-channel work -- bias, the GroupNorm partial statistics -- is in-lane arithmetic,
+// and no trip through LDS is needed to reach the NHWC rows: neighbouring lanes (channels c, c + 1) swap one value per
+// pixel pair through DPP, after which the even lane holds both channels at pixel r and the odd lane both at pixel r + 1.
+// Each then loads / stores ONE dword (two 16-bit channels); the 16 lane pairs of a half-wave cover 64 contiguous bytes
+// of an output pixel.  Per thread and tile: 8 loads (residual), 8 stores, ~20 VALU per pixel pair -- against two
+// block-wide passes through a 35 KB LDS tile, four barriers and half the waves idle in the staged form.
+// Statistics: pivoted (mean, M2) over the lane's 16 values per channel, equal-count merges lane pair -> half-waves ->
+// the two waves that share the channels (through `red`, [2][MT][128][2] floats of LDS).  All 256 threads must call;
+// every wave must be past its last read of the LDS that `red` overlays.
+template <class OT, int MT>
+__device__ __forceinline__ void halo16_out_direct(const ConvArgs& a, f32x16 (&acc)[MT][2][2], float* red, int m_tl, int W,
+                                                  int n0, int bsmp, int tile0, int tiles_x) {
+    static_assert(sizeof(OT) == 2, "16-bit storage only");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kh = lane >> 5;
+    const bool odd = li & 1;
+    const int Cout = a.Cout;
+    const bool has_res = a.res != nullptr;
+    const unsigned* resw = reinterpret_cast<const unsigned*>(reinterpret_cast<const OT*>(a.res) + (int64_t)m_tl * Cout);
+    unsigned* outw = reinterpret_cast<unsigned*>(reinterpret_cast<OT*>(a.out) + (int64_t)m_tl * Cout);
+    // dword offset of this lane's channel pair at tile pixel 0, plus its pixel inside the 4-pixel group (odd + 4 kh)
+    const int lane_off = ((odd ? 1 : 0) + 4 * kh) * (Cout >> 1) + ((n0 + wn * 64 + (li & ~1)) >> 1);
+    float bq[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = n0 + wn * 64 + j * 32 + (li & ~1);
+        bq[j][0] = a.bias ? a.bias[c] : 0.f;
+        bq[j][1] = a.bias ? a.bias[c + 1] : 0.f;
+        if (a.bias2) {
+            const float* b2 = a.bias2 + (int64_t)bsmp * a.bias2_stride + c;
+            bq[j][0] += b2[0];
+            bq[j][1] += b2[1];
+        }
+    }
+    const float scale = a.scale;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        float piv[2][2], s1[2][2], s2[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { piv[j][e] = 0.f; s1[j][e] = 0.f; s2[j][e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // tile row of pixel pair p: rho = 2 (p & 1) + 8 ((p >> 1) & 1) + 16 (p >> 2) [+ odd + 4 kh]: image row p >> 2
+            const int row_off = ((t * 8 + 2 * (wm * 2 + i)) * W) * (Cout >> 1) + lane_off;
+            const int row_step = W * (Cout >> 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                unsigned rres[8];
+                int off[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    off[p] = row_off + (p >> 2) * row_step + (2 * (p & 1) + 8 * ((p >> 1) & 1)) * (Cout >> 1) + j * 16;
+                    if (has_res) rres[p] = resw[off[p]];
+                }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const float lo = acc[t][i][j][2 * p], hi = acc[t][i][j][2 * p + 1];
+                    const float send = odd ? lo : hi;
+                    const float recv = __builtin_bit_cast(
+                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));
+                    float v0 = (odd ? recv : lo) + bq[j][0];          // channel pair (c, c + 1) at this lane's pixel
+                    float v1 = (odd ? hi : recv) + bq[j][1];
+                    if (has_res) {
+                        float r0, r1;
+                        St<OT>::unpack2(rres[p], r0, r1);
+                        v0 += r0;
+                        v1 += r1;
+                    }
+                    v0 *= scale;
+                    v1 *= scale;
+                    const unsigned w = St<OT>::pack2(v0, v1);
+                    outw[off[p]] = w;
+                    St<OT>::unpack2(w, v0, v1);                        // statistics of what was stored
+                    if (i == 0 && p == 0) { piv[j][0] = v0; piv[j][1] = v1; }
+                    const float d0 = v0 - piv[j][0], d1 = v1 - piv[j][1];
+                    s1[j][0] += d0; s2[j][0] = fmaf(d0, d0, s2[j][0]);
+                    s1[j][1] += d1; s2[j][1] = fmaf(d1, d1, s2[j][1]);
+                }
+            }
+        }
+        if (!a.stats) continue;
+        // 16 values per lane and channel -> lane pair (32) -> half-waves (64 = this wave's pixels of the sub-tile)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float mean = piv[j][e] + s1[j][e] * (1.f / 16);
+                float m2 = fmaxf(s2[j][e] - s1[j][e] * s1[j][e] * (1.f / 16), 0.f);
+                {
+                    const float mo = __builtin_bit_cast(
+                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mean), 0xB1, 0xF, 0xF, false));
+                    const float qo = __builtin_bit_cast(
+                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m2), 0xB1, 0xF, 0xF, false));
+                    const float d = mo - mean;
+                    m2 = m2 + qo + d * d * 8.f;
+                    mean = 0.5f * (mean + mo);
+                }
+                {
+                    const float mo = __shfl_xor(mean, 32), qo = __shfl_xor(m2, 32);
+                    const float d = mo - mean;
+                    m2 = m2 + qo + d * d * 16.f;
+                    mean = 0.5f * (mean + mo);
+                }
+                if (kh == 0 && !odd) {
+                    float* dst = red + (((wm * MT + t) * 128) + wn * 64 + j * 32 + li + e) * 2;
+                    dst[0] = mean;
+                    dst[1] = m2;
+                }
+            }
+    }
+    if (!a.stats) return;
+    __syncthreads();
+    if (tid < 128) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const float ma = red[((0 * MT + t) * 128 + tid) * 2], qa = red[((0 * MT + t) * 128 + tid) * 2 + 1];
+            const float mb = red[((1 * MT + t) * 128 + tid) * 2], qb = red[((1 * MT + t) * 128 + tid) * 2 + 1];
+            const float d = mb - ma;
+            float* dst = a.stats + (((int64_t)bsmp * a.stats_nblk + tile0 + t * tiles_x) * Cout + n0 + tid) * 2;
+            dst[0] = 0.5f * (ma + mb);
+            dst[1] = qa + qb + d * d * 32.f;
+        }
+    }
+}
+
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
@@ -2132,6 +2261,17 @@ __device__ __forceinline__ u32x4 widen_quad(typename RawQuad<ST>::type t) {
     }
 }
 
+#ifdef FLOWSE_TS
+// Measurement build only (-DFLOWSE_TS): per-block phase timestamps of the 16-bit halo kernel (s_memtime) + HW ids.
+__device__ unsigned long long g_ts[8192 * 10];
+extern "C" int flowse_debug_ts(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ts), (size_t)n * 8) == hipSuccess ? 0 : 1;
+}
+#define FLOWSE_TS_MARK(k) if (ts_on) ts[k] = __builtin_amdgcn_s_memtime();
+#else
+#define FLOWSE_TS_MARK(k)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // Single-plane (bf16 / half) LDS-halo 3x3 kernel, built for THREE blocks per CU.
 //
@@ -2158,6 +2298,12 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
     constexpr int BTILE = BN * ROWB;                       // one tap's weight tile
     constexpr unsigned ES = sizeof(IT);
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef FLOWSE_TS
+    unsigned long long ts[10];
+    const bool ts_on = a.H == 256 && a.C1 + a.C2 == 128 && GN;
+    for (int k = 0; k < 10; ++k) ts[k] = 0;
+#endif
+    FLOWSE_TS_MARK(0)
     char* Hs = reinterpret_cast<char*>(smem);              // [TROWS + 2][HPITCH]
     char* Bs = Hs + (TROWS + 2) * HPITCH;                           // [2 buffers][BN][ROWB]
 
@@ -2176,28 +2322,37 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
     const int m_tl = (b * H + y0) * W + x0;
 
     const int col4 = tid & 7, row0 = tid >> 3;             // halo staging: 8 channel quads x 32 rows per pass
-    unsigned hpix[H_LOADS];                                // pixel offset of this thread's halo quads inside the window
-    int hlds[H_LOADS];                                     // their LDS byte offset (-1: past the last halo pixel)
+    // Window row / column of this thread's halo quads, two quads per register (hy | hx << 8 in 16 bits each): the pixel
+    // offset (hy W + hx) and the LDS offset are re-derived where used, once per chunk -- registers matter more here.
+    unsigned hyx[(H_LOADS + 1) / 2];
     unsigned hin = 0;                                      // bit q: quad q lies inside the image
+    unsigned hval = 0;                                     // bit q: quad q is a halo pixel at all (hr < HROWS)
 #pragma unroll
     for (int q = 0; q < H_LOADS; ++q) {
         const int hr = row0 + 32 * q;
         const int hy = hr / 18, hx = hr - hy * 18;
         const bool in = hr < HROWS && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
-        hpix[q] = (unsigned)(hy * W + hx);
-        hlds[q] = hr < HROWS ? hy * HPITCH + hx * ROWB + col4 * 8 : -1;
+        const unsigned pk = (unsigned)hy | ((unsigned)hx << 8);
+        if (q & 1) hyx[q >> 1] |= pk << 16; else hyx[q >> 1] = pk;
         hin |= in ? (1u << q) : 0u;
+        hval |= hr < HROWS ? (1u << q) : 0u;
     }
+    // `fence_hyx()` makes the packed coordinates opaque at the point of use: without it hipcc hoists every derived
+    // per-quad offset out of the chunk loop and, out of registers, parks them in scratch (reloaded under vmcnt(0)).
+    auto fence_hyx = [&]() {
+#pragma unroll
+        for (int k = 0; k < (H_LOADS + 1) / 2; ++k) asm volatile("" : "+v"(hyx[k]));
+    };
+    auto h_y = [&](int q) { return (hyx[q >> 1] >> ((q & 1) * 16)) & 0xffu; };
+    auto h_x = [&](int q) { return (hyx[q >> 1] >> ((q & 1) * 16 + 8)) & 0xffu; };
     const int bcol = tid & 3, brow0 = tid >> 2;            // weight staging: 4 x 16-byte columns, rows brow0 + 64 q
     const unsigned bvo0 = (unsigned)((n0 + brow0) * 9 * nchunks * 64 + bcol * 16), bvo_step = (unsigned)(64 * 9 * nchunks * 64);
     const int64_t wbase = (int64_t)m_tl - W - 1;
     const int wpix = (TROWS + 1) * W + 18;
     const IT* in1p = reinterpret_cast<const IT*>(a.in1);
     const IT* in2p = reinterpret_cast<const IT*>(a.in2);
-    const __amdgpu_buffer_rsrc_t rsrc1 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<IT*>(in1p + wbase * C1), 0, wpix * C1 * (int)ES, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<IT*>(C2 ? in2p + wbase * C2 : in1p), 0, C2 ? wpix * C2 * (int)ES : 0, 0x00020000);
+    const IT* win1 = in1p + wbase * C1;                   // window origins of the two inputs (block-uniform)
+    const IT* win2 = C2 ? in2p + wbase * C2 : in1p;
     const __amdgpu_buffer_rsrc_t rsrcw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wq), 0, a.Cout * 9 * nchunks * 64, 0x00020000);
 
@@ -2206,13 +2361,24 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
     float4 g_mu, g_sc, g_be;
     auto gloadH = [&](int chunk) {
         const int c0 = chunk * KC;
-        const bool second = c0 >= C1;
+        const bool second = c0 >= C1;                      // block-uniform: the descriptor is built from scalars, per chunk
         const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * ES;
         const unsigned cs = (unsigned)(second ? C2 : C1);
+        // the window origin goes through readfirstlane: under SGPR pressure hipcc otherwise keeps it in VGPRs and wraps
+        // every load in a waterfall loop
+        const uint64_t wsel = reinterpret_cast<uint64_t>(second ? win2 : win1);
+        const uint64_t wuni = (uint64_t)__builtin_amdgcn_readfirstlane((unsigned)wsel) |
+                              ((uint64_t)__builtin_amdgcn_readfirstlane((unsigned)(wsel >> 32)) << 32);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<IT*>(wuni), 0, __builtin_amdgcn_readfirstlane(wpix * (int)cs * (int)ES), 0x00020000);
+        unsigned hin_l = hin;
+        asm volatile("" : "+v"(hin_l));                    // opaque, like the coordinates: no hoisted per-quad masks
+        fence_hyx();
 #pragma unroll
         for (int q = 0; q < H_LOADS; ++q) {
-            const unsigned off = ((hin >> q) & 1u) ? (hpix[q] * cs + (unsigned)col4 * 4u) * ES : OOB;
-            rh[q] = second ? buf_ld_raw<IT>(rsrc2, off, soff) : buf_ld_raw<IT>(rsrc1, off, soff);
+            const unsigned pix = h_y(q) * (unsigned)W + h_x(q);
+            const unsigned off = ((hin_l >> q) & 1u) ? (pix * cs + (unsigned)col4 * 4u) * ES : OOB;
+            rh[q] = buf_ld_raw<IT>(rsrc, off, soff);
         }
         if (GN) {
             const int cg = c0 + col4 * 4;
@@ -2242,9 +2408,11 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
         rh[Q].y = (unsigned)h[2] | ((unsigned)h[3] << 16);
     };
     auto lstoreH = [&]() {
+        fence_hyx();
 #pragma unroll
         for (int q = 0; q < H_LOADS; ++q)
-            if (hlds[q] >= 0) *reinterpret_cast<uint2*>(Hs + hlds[q]) = make_uint2(rh[q].x, rh[q].y);
+            if ((hval >> q) & 1u)
+                *reinterpret_cast<uint2*>(Hs + h_y(q) * HPITCH + h_x(q) * ROWB + col4 * 8) = make_uint2(rh[q].x, rh[q].y);
     };
     const int S_all = nchunks * 9;
     auto gloadB = [&](int s) {
@@ -2285,6 +2453,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
     lstoreH();
     lstoreB(0);
     __syncthreads();
+    FLOWSE_TS_MARK(1)
 
     // One tap.  TAP is a literal: the nine taps of a chunk are straight-line code, no load sits under a branch.  The
     // next tap's weights are requested first (pinned in front of the MFMAs), the next chunk's halo at tap 1; its six
@@ -2332,12 +2501,21 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         FLOWSE_TAP16(0) FLOWSE_TAP16(1) FLOWSE_TAP16(2) FLOWSE_TAP16(3) FLOWSE_TAP16(4)
         FLOWSE_TAP16(5) FLOWSE_TAP16(6) FLOWSE_TAP16(7) FLOWSE_TAP16(8)
+#ifdef FLOWSE_TS
+        if (ts_on && chunk < 4) ts[2 + chunk] = __builtin_amdgcn_s_memtime();
+#endif
     }
 #undef FLOWSE_TAP16
 
+    if constexpr (sizeof(OT) == 2) {
+        // ---- 16-bit storage: output straight from the accumulators (halo16_out_direct)
+        const int bsmp = m_tl / HW;
+        const int rem = m_tl - bsmp * HW;
+        const int tile0 = ((rem / W) >> 3) * (W >> 4) + ((rem % W) >> 4);                  // 8 x 16 statistics tiles, row-major
+        halo16_out_direct<OT, MT>(a, acc, smem, m_tl, W, n0, bsmp, tile0, W >> 4);
+    } else {
     // ---- epilogue in two halves of 64 output channels (C tile [128][68] floats = 35 KB instead of 68 KB).  Half h is
     // held by the waves with wn == h; then all 256 threads run the shared output stage on it.
-    {
         constexpr int CROW = 68;
         float* Cs = smem;
         float* red = smem + 128 * CROW;
@@ -2365,6 +2543,17 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
             }
         }
     }
+#ifdef FLOWSE_TS
+    if (ts_on) {
+        __syncthreads();
+        ts[6] = __builtin_amdgcn_s_memtime();
+        ts[7] = __builtin_amdgcn_s_getreg(63492);          // HW_ID
+        ts[8] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+        ts[9] = blockIdx.x;
+        if (tid == 0 && bid < 8192)
+            for (int k = 0; k < 10; ++k) g_ts[bid * 10 + k] = ts[k];
+    }
+#endif
 }
 
 template <bool F16>
@@ -2381,7 +2570,9 @@ static int launch_halo16(const ConvArgs& a, hipStream_t s) {
     const int grid = (int)(M / (mt2 ? 256 : 128)) * (a.Cout / 128);
     const size_t lds_stage = (size_t)(mt2 ? 18 : 10) * (18 * 80 + 96) + (size_t)2 * 128 * 80;
     const size_t lds_epi = ((size_t)128 * 68 + 4 * 64 * 2) * sizeof(float);
-    const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    size_t lds = (a.in_dt == DT_F32 && lds_epi > lds_stage) ? lds_epi : lds_stage;      // the staged epilogue is the fp32-storage one
+    static const size_t lds_min = getenv("FLOWSE_HALO16_LDS") ? (size_t)atoi(getenv("FLOWSE_HALO16_LDS")) : 0;   // occupancy probe
+    if (lds < lds_min) lds = lds_min;
 #define FLOWSE_LH16(GNF, IT, OT, MTV)                                                                             \
     {                                                                                                             \
         if (const int rc = allow_lds<&conv3x3_halo16_kernel<GNF, F16, IT, OT, MTV>>(lds)) return rc;              \

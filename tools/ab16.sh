@@ -7,7 +7,7 @@ for v in 0 1; do
   python - <<PY
 import json
 j=[json.loads(l) for l in open('gpurun_out/r2_ab16_$v.json') if l.startswith('{')][-1]
-print('mt1=$v bf16', round(j['value']), round(j['ms_per_step'],2), j['roofline']['avg_launch_ms'], j['roofline']['frac'])
+print('mt1=$v bf16', round(j['value']), round(j['ms_per_step'],2))
 PY
-  grep "conv1_3x3_gn@256x256\|conv0_3x3_gn@256x256:256\|conv1_3x3_gn@64x64" gpurun_out/r2_ab16_$v.err
+  grep "conv1_3x3_gn@256x256\|conv0_3x3_gn@256x256:256\|conv1_3x3_gn@64x64\|conv1_3x3_gn@128x128:128" gpurun_out/r2_ab16_$v.err
 done
