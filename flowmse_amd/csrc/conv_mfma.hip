@@ -2268,8 +2268,16 @@ extern "C" int flowse_debug_ts(unsigned long long* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ts), (size_t)n * 8) == hipSuccess ? 0 : 1;
 }
 #define FLOWSE_TS_MARK(k) if (ts_on) ts[k] = __builtin_amdgcn_s_memtime();
+// phase marks inside taps 2..7 of chunk 1: ts[k] accumulates the time since the previous mark
+#define FLOWSE_TS_TAP(k)                                                  \
+    if (ts_on && chunk == 1 && tap >= 2 && tap <= 7) {                    \
+        const unsigned long long now = __builtin_amdgcn_s_memtime();      \
+        if (k >= 2) ts[k] += now - ts_last;                               \
+        ts_last = now;                                                    \
+    }
 #else
 #define FLOWSE_TS_MARK(k)
+#define FLOWSE_TS_TAP(k)
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -2299,7 +2307,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
     constexpr unsigned ES = sizeof(IT);
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef FLOWSE_TS
-    unsigned long long ts[10];
+    unsigned long long ts[10], ts_last = 0;
     const bool ts_on = a.H == 256 && a.C1 + a.C2 == 128 && GN;
     for (int k = 0; k < 10; ++k) ts[k] = 0;
 #endif
@@ -2367,8 +2375,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
         // the window origin goes through readfirstlane: under SGPR pressure hipcc otherwise keeps it in VGPRs and wraps
         // every load in a waterfall loop
         const uint64_t wsel = reinterpret_cast<uint64_t>(second ? win2 : win1);
-        const uint64_t wuni = (uint64_t)__builtin_amdgcn_readfirstlane((unsigned)wsel) |
-                              ((uint64_t)__builtin_amdgcn_readfirstlane((unsigned)(wsel >> 32)) << 32);
+        const uint64_t wuni = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wsel) |
+                              ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wsel >> 32)) << 32);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<IT*>(wuni), 0, __builtin_amdgcn_readfirstlane(wpix * (int)cs * (int)ES), 0x00020000);
         unsigned hin_l = hin;
@@ -2463,6 +2471,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
         constexpr int tap = TAP;                                                                                     \
         const int s = chunk * 9 + tap;                                                                               \
         const int buf = s & 1;                                                                                       \
+        FLOWSE_TS_TAP(0)                                                                                             \
         gloadB(min(s + 1, S_all - 1));                                                                               \
         if (tap == 1) gloadH(min(chunk + 1, nchunks - 1));                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -2485,14 +2494,18 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
             }                                                                                                        \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
+        FLOWSE_TS_TAP(2)                                                                                             \
         /* GroupNorm of the next chunk's quads, in the shadow of the MFMAs just issued: taps 2..7 take them all */   \
         if (tap >= 2 && tap <= 7) {                                                                                  \
             constexpr int QPT = (H_LOADS + 5) / 6;                                                                   \
             _Pragma("unroll") for (int qq = 0; qq < QPT; ++qq)                                                       \
                 if ((tap - 2) * QPT + qq < H_LOADS) xform1((tap - 2) * QPT + qq);                                    \
         }                                                                                                            \
+        FLOWSE_TS_TAP(3)                                                                                             \
         lstoreB(buf ^ 1);                                /* at the very last tap: a spare tile into the idle buffer */ \
+        FLOWSE_TS_TAP(4)                                                                                             \
         __syncthreads();                                                                                             \
+        FLOWSE_TS_TAP(5)                                                                                             \
         if (tap == 8) {                                  /* everyone is done with this chunk's halo */              \
             lstoreH();                                                                                               \
             __syncthreads();                                                                                         \
@@ -2501,11 +2514,9 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         FLOWSE_TAP16(0) FLOWSE_TAP16(1) FLOWSE_TAP16(2) FLOWSE_TAP16(3) FLOWSE_TAP16(4)
         FLOWSE_TAP16(5) FLOWSE_TAP16(6) FLOWSE_TAP16(7) FLOWSE_TAP16(8)
-#ifdef FLOWSE_TS
-        if (ts_on && chunk < 4) ts[2 + chunk] = __builtin_amdgcn_s_memtime();
-#endif
     }
 #undef FLOWSE_TAP16
+    FLOWSE_TS_MARK(6)
 
     if constexpr (sizeof(OT) == 2) {
         // ---- 16-bit storage: output straight from the accumulators (halo16_out_direct)
@@ -2546,10 +2557,9 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(Co
 #ifdef FLOWSE_TS
     if (ts_on) {
         __syncthreads();
-        ts[6] = __builtin_amdgcn_s_memtime();
-        ts[7] = __builtin_amdgcn_s_getreg(63492);          // HW_ID
-        ts[8] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
-        ts[9] = blockIdx.x;
+        ts[7] = __builtin_amdgcn_s_memtime();
+        ts[8] = __builtin_amdgcn_s_getreg(63492);          // HW_ID
+        ts[9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
         if (tid == 0 && bid < 8192)
             for (int k = 0; k < 10; ++k) g_ts[bid * 10 + k] = ts[k];
     }

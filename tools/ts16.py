@@ -30,19 +30,19 @@ if __name__ == "__main__":
     t = t[t[:, 0] > 0]
     print("blocks with marks:", len(t))
     t0 = t[:, 0].min()
-    span = t[:, 6].max() - t0
-    print(f"launch span {span} ticks")
-    ph = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3], t[:, 5] - t[:, 4],
-                   t[:, 6] - t[:, 5], t[:, 6] - t[:, 0]], 1)
-    names = ["prologue", "chunk0", "chunk1", "chunk2", "chunk3", "epilogue", "total"]
+    span = t[:, 7].max() - t0
+    print('launch span', span)
+    ph = np.stack([t[:, 1] - t[:, 0], t[:, 6] - t[:, 1], t[:, 7] - t[:, 6], t[:, 7] - t[:, 0],
+                   t[:, 2] / 6, t[:, 3] / 6, t[:, 4] / 6, t[:, 5] / 6, (t[:, 2] + t[:, 3] + t[:, 4] + t[:, 5]) / 6], 1)
+    names = ["prologue", "mainloop", "epilogue", "total", "tap:rd+mfma", "tap:gn", "tap:w-wait+wr", "tap:barrier", "tap:total"]
     for k, n in enumerate(names):
         v = ph[:, k]
-        print(f"{n:9s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}  p90 {np.percentile(v, 90):9.0f}")
-    hw = t[:, 7]
+        print(f"{n:14s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}  p90 {np.percentile(v, 90):9.0f}")
+    hw = t[:, 8]
     cu = (hw >> 8) & 0xF
     sh = (hw >> 12) & 0x1
     se = (hw >> 13) & 0x7
-    xcc = t[:, 8] & 0xF
+    xcc = t[:, 9] & 0xF
     key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
     print("distinct CUs:", len(np.unique(key)))
     # one CU: list its blocks in start order
@@ -50,11 +50,10 @@ if __name__ == "__main__":
         rows = t[key == kk]
         rows = rows[np.argsort(rows[:, 0])]
         print(f"CU key {kk}: {len(rows)} blocks")
-        for r in rows[:12]:
-            print("   start %8d  pro %6d  chunks %6d %6d %6d %6d  epi %6d  end %8d  simd-wave %x" %
-                  (r[0] - t0, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], r[6] - r[5], r[6] - t0, r[7] & 0xff))
+        for r in rows[:8]:
+            print("   start %8d  pro %6d  main %6d  epi %6d  end %8d" % (r[0] - t0, r[1] - r[0], r[6] - r[1], r[7] - r[6], r[7] - t0))
     busy = []
     for kk in np.unique(key):
         rows = t[key == kk]
-        busy.append((rows[:, 6] - rows[:, 0]).sum() / max(1, rows[:, 6].max() - rows[:, 0].min()))
+        busy.append((rows[:, 7] - rows[:, 0]).sum() / max(1, rows[:, 7].max() - rows[:, 0].min()))
     print("mean concurrently-resident blocks per CU:", np.mean(busy))
