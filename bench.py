@@ -274,7 +274,7 @@ def main():
                      "GroupNorm+SiLU input, weights streamed from L2 in MFMA fragment order)" if form else
                      "flowse::conv3x3_halo_kernel<2,2,2,2,2> (fp32 implicit-GEMM 3x3 conv, 128x128 tile, LDS halo, "
                      "fused GroupNorm+SiLU input)" if args.precision == "fp32" else
-                     "flowse::conv3x3_halo_bf16_kernel (16-bit operand variant of the halo kernel)")
+                     "flowse::conv3x3_halo16_kernel / conv3x3_halo_bf16_kernel (16-bit operand LDS-halo 3x3 kernels)")
             issue = {"F(4,3)": 0.5, "F(2,3)": 2.0 / 3.0, None: 3.0 if args.precision == "bf16x3" else 1.0}[form]
             issued = ach * issue
             peak = PEAK_FP32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_16BIT_MATRIX_TFLOPS
@@ -354,7 +354,7 @@ def main():
                     tf = dm["issued"] / (dm["ms"] * 1e-3) / 1e12
                     gbs = dm["bytes"] / (dm["ms"] * 1e-3) / 1e9
                     alts[mode]["roofline"] = {
-                        "kernel": "flowse::conv3x3_halo_bf16_kernel (LDS-halo 3x3, 16-bit MFMA operands, fused GroupNorm+SiLU input)",
+                        "kernel": "flowse::conv3x3_halo16_kernel / conv3x3_halo_bf16_kernel (LDS-halo 3x3, 16-bit MFMA operands, fused GroupNorm+SiLU input)",
                         "bound": "hbm" if gbs / HBM_PEAK_GBS > tf / PEAK_16BIT_MATRIX_TFLOPS else "mfma",
                         "achieved_TFLOPs_issued": tf, "mfma_peak_TFLOPs": PEAK_16BIT_MATRIX_TFLOPS,
                         "mfma_frac": tf / PEAK_16BIT_MATRIX_TFLOPS,

@@ -94,6 +94,8 @@ def test_block_handle_rejects_misuse():
 MODES16 = [("bf16", 2.5e-2), ("fp16", 3.5e-3)]
 CASES16 = [  # tag, cin, cout, (B, C, H, W), kwargs, two-source split
     ("plain_halo", 128, 128, (2, 128, 64, 128), {}, None),
+    ("plain_halo_16x16_tile", 128, 128, (8, 128, 128, 128), {}, None),      # >= 512 blocks of 256 pixels: two sub-tiles per block
+    ("concat_halo_16x16_tile", 256, 128, (8, 256, 128, 128), {}, 128),
     ("concat_halo_shortcut", 256, 128, (2, 256, 64, 128), {}, 128),
     ("concat384_straddle", 384, 128, (2, 384, 64, 128), {}, 256),
     ("small_flat_splitk", 256, 256, (2, 256, 8, 8), {}, None),

@@ -86,9 +86,9 @@ def main(tag):
         cyc = m["GRBM_GUI_ACTIVE"] / 8.0
         with open(os.path.join(P, f"{tag}_pmc_dominant_kernel.txt"), "w") as f:
             f.write("# rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
-                    "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- python bench.py --steps 1 --warmup 0 "
+                    "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- python bench.py --steps 1 --warmup 1 "
                     "--no-cpu-baseline --no-alt\n")
-            f.write(f"# kernel: {dom[0]}, {len(durs)} launches (one sampler pass at [8,1,256,256], N=5), "
+            f.write(f"# kernel: {dom[0]}, {len(durs)} launches (warm-up, capture, timed and event-bracketed sampler passes at [8,1,256,256], N=5), "
                     f"avg {dur / 1e3:.1f} us (profiled run)\n")
             for k in sorted(m):
                 f.write(f"{k:28s} per launch {m[k]:.4e}\n")
