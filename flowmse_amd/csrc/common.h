@@ -231,6 +231,13 @@ struct ConvArgs {
     // tile to `partial` [ksplit][B*H*W][Cout]; splitk_reduce sums the slices and applies the epilogue.
     int ksplit = 1;
     float* partial = nullptr;
+    // In-launch reduction (optional): `sk_ticket` = one zero-initialised counter per output tile (gridDim.x of them).
+    // Every slice stores its raw tile, then takes a ticket; the slice that takes the LAST one sums all slices in slice
+    // order (the result does not depend on the arrival order) and runs the epilogue -- no splitk_reduce launch.  The
+    // counter is reset by that block, so the buffer serves every launch on the stream.  `sk_group` = flat pixels per
+    // statistics block (conv_splitk_stats_group) or 0 for one statistics block per 8 x 16 pixel tile (F(4,3) slices).
+    unsigned* sk_ticket = nullptr;
+    int sk_group = 0;
     // fused GroupNorm statistics of the OUTPUT (optional): per-(sample, pixel tile, channel) sum / sum of squares
     // written to stats[((b * stats_nblk + tile) * Cout + c) * 2 + {0,1}], the layout gn_finalize consumes.
     // Only honoured when H*W % 128 == 0 and ksplit == 1 (see conv_fused_stats_blocks).
@@ -289,6 +296,12 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce = true);
 int launch_splitk_reduce(const ConvArgs& a, hipStream_t s);
 // number of K slices launch_conv will use for this shape (1 = no split) and the partial-buffer size in floats
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps);
+// split-K launches reduce inside the launch (ConvArgs::sk_ticket) when FLOWSE_SPLITK_IN_LAUNCH=1 (slower, measured)
+bool conv_splitk_in_launch();
+// flat pixels per statistics block of a split-K conv's output
+int conv_splitk_stats_group(int HW);
+// true when this 3x3 shape runs as slices of the F(4,3) kernel (statistics then come per 8 x 16 tile when reduced in-launch)
+bool conv_splitk_is_wino(int B, int H, int W, int Cin, int Cout, int taps);
 // true when the 4-channel input conv runs on the matrix cores (then it also emits fused GroupNorm statistics,
 // H*W/128 partial blocks per sample)
 bool conv_cin4_uses_mfma(int B, int H, int W, int Cout, int taps);

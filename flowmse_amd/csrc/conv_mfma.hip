@@ -121,7 +121,7 @@ __device__ __forceinline__ void conv_epilogue_with(const ConvArgs& a, float* sme
     }
     scatter(Cs, CROW);                         // accumulators -> Cs[tile row][channel]
     __syncthreads();
-    if (a.partial) {                           // split-K slice: raw partial sums, epilogue in splitk_reduce
+    if (a.partial) {                           // split-K slice: raw partial sums
         if (ncol) {
             float* dst = a.partial + (int64_t)split * M * a.Cout;
             for (int rr = er0; rr < BM; rr += RPP) {
@@ -129,6 +129,85 @@ __device__ __forceinline__ void conv_epilogue_with(const ConvArgs& a, float* sme
                 if (m >= M) break;
                 *reinterpret_cast<float4*>(dst + (int64_t)m * a.Cout + n) =
                     *reinterpret_cast<const float4*>(Cs + rr * CROW + ec4 * 4);
+            }
+        }
+        if (!a.sk_ticket) return;              // two-pass form: splitk_reduce sums the slices and runs the epilogue
+        // ---- in-launch reduction.  Release the tile, take a ticket; the block that takes the last one of this tile
+        // acquires, sums the slices 0 .. ks-1 in that order (its own included, re-read: the sum is independent of which
+        // slice arrived last), applies bias / per-sample bias / residual / scale, stores, and leaves the GroupNorm
+        // partial statistics of what it stored -- exactly the layouts the two-pass reduction kernels write.
+        __threadfence();
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);            // the C tile is free again
+        if (tid == 0) {
+            const unsigned ks = gridDim.y;
+            const unsigned t = atomicAdd(a.sk_ticket + blockIdx.x, 1u);
+            if (t == ks - 1) a.sk_ticket[blockIdx.x] = 0;   // ready for the next launch on the stream
+            *flag = (t == ks - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        const int last = *flag;
+        if (!last) return;
+        __threadfence();
+        __syncthreads();                                     // everyone has read the flag: Cs may be overwritten
+        static_assert(BM == 128, "tile rows");
+        const int ks = (int)gridDim.y;
+        const int64_t slice = (int64_t)M * a.Cout;
+        if (ncol) {
+            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll 2
+            for (int k = 0; k < NR; ++k) {
+                const int rr = er0 + k * RPP;
+                const int m = rowW ? m0 + (rr >> 4) * rowW + (rr & 15) : m0 + rr;
+                if (m >= M) break;
+                const int64_t i4 = (int64_t)m * a.Cout + n;
+                float4 v = *reinterpret_cast<const float4*>(a.partial + i4);
+#pragma unroll 8
+                for (int s = 1; s < ks; ++s) {               // independent loads: many in flight
+                    const float4 t = *reinterpret_cast<const float4*>(a.partial + s * slice + i4);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                if (a.bias2) {
+                    const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)(m / HW) * a.bias2_stride + n);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                if (a.res) {
+                    const float4 t = St<OT>::ld4(resp + i4);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
+                St<OT>::st4(outp + i4, v);
+                if (a.stats) *reinterpret_cast<float4*>(Cs + rr * CROW + ec4 * 4) = St<OT>::rnd4(v);
+            }
+        }
+        if (!a.stats) return;
+        __syncthreads();
+        // statistics: a thread = (channel, every `NT / BN`-th group of GR tile rows); two passes over the LDS tile (exact
+        // mean, then M2).  Flat tiles: groups of sk_group flat pixels (never straddling a sample: sk_group | HW);
+        // 8 x 16 tiles: the whole tile is one block of the sample's tile grid.
+        const int GR = rowW ? BM : a.sk_group;
+        const int c = tid % BN, g0 = tid / BN;
+        if (n0 + c < a.Cout) {
+            for (int g = g0; g * GR < BM; g += NT / BN) {
+                const int r0 = g * GR;
+                const int mf = rowW ? m0 : m0 + r0;          // first pixel of the group
+                if (mf >= M) break;
+                float sum = 0.f;
+                for (int r = 0; r < GR; ++r) sum += Cs[(r0 + r) * CROW + c];
+                const float mean = sum / (float)GR;
+                float m2 = 0.f;
+                for (int r = 0; r < GR; ++r) {
+                    const float d = Cs[(r0 + r) * CROW + c] - mean;
+                    m2 = fmaf(d, d, m2);
+                }
+                const int bsmp = mf / HW;
+                const int rem = mf - bsmp * HW;
+                const int blk = rowW ? ((rem / rowW) >> 3) * (rowW >> 4) + ((rem % rowW) >> 4) : rem / GR;
+                float* dst = a.stats + (((int64_t)bsmp * a.stats_nblk + blk) * a.Cout + n0 + c) * 2;
+                dst[0] = mean;
+                dst[1] = m2;
             }
         }
         return;
@@ -1135,10 +1214,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(ConvArgs a, in
 
 // Split-K policy: images so small that the 128x128 tiling yields < 256 blocks (one per CU) are sliced along K
 // until ~512 blocks exist, keeping >= 4 K steps per slice.
+// Measured on MI355X (round 2): the in-launch form removes 75 (B = 8) / 111 (B = 1) launches per network evaluation
+// and is SLOWER -- 137.4 vs 122.7 ms per step at [8,1,256,256], 44.5 vs 33.4 ms at [1,1,256,256]: the last slice of a
+// tile pulls ks x 64 KB through ONE CU's L1 (>= 8 us at 64 B/clk) after its own K loop, while the two-pass kernel
+// spreads the same bytes over every CU in ~4 us.  So the two-pass form stays the default; FLOWSE_SPLITK_IN_LAUNCH=1
+// selects the in-launch form (same results to the last bit of the summation order, tests/test_gpu_model.py).
+bool conv_splitk_in_launch() {
+    static const bool on = getenv("FLOWSE_SPLITK_IN_LAUNCH") != nullptr;
+    return on;
+}
+int conv_splitk_stats_group(int HW) { return sk_pixels_per_block(HW); }
+
 int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps) {
     const int HW = H * W;
     if (Cout & 3) return 0;
-    if (conv_ksplit(B, H, W, Cin, Cout, taps) != 1) {      // statistics come from the split-K reduction pass
+    if (conv_ksplit(B, H, W, Cin, Cout, taps) != 1) {      // statistics come from the split-K reduction
+        if (conv_splitk_in_launch() && conv_splitk_is_wino(B, H, W, Cin, Cout, taps)) return HW / 128;   // per 8 x 16 tile
         const int PB = sk_pixels_per_block(HW);
         return ((HW % PB) == 0 && Cout / 4 <= 256) ? HW / PB : 0;
     }
@@ -1183,6 +1274,10 @@ int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     const int per = (int)((steps + ks - 1) / ks);
     ks = (steps + per - 1) / per;
     return (int)ks;
+}
+
+bool conv_splitk_is_wino(int B, int H, int W, int Cin, int Cout, int taps) {
+    return conv_wino_default_f43() && conv_supports_wino(B, H, W, Cin, 0, Cout, taps) && wino_plan(B, H, W, Cin, Cout, taps) >= 2;
 }
 
 static const bool g_no_halo = getenv("FLOWSE_NO_HALO_CONV") != nullptr;

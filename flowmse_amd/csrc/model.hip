@@ -141,6 +141,8 @@ struct ProfAcc {
 
 using namespace flowse;
 
+static constexpr int SK_TICKETS = 4096;   // split-K launches have < 256 tiles by policy; far above any grid.x they use
+
 struct flowse_model {
     flowse_config cfg;
     std::vector<Module> mods;
@@ -170,6 +172,7 @@ struct flowse_model {
     size_t d_ts_floats = 0;
     std::map<std::tuple<int, int, int>, Plan> plans;
     CallBlock* d_call = nullptr;           // per-call arguments of the boundary kernels, in device memory
+    unsigned* d_ticket = nullptr;          // split-K arrival counters, one per output tile (zero between launches)
     int device = -1;                       // HIP device that owns every d_* buffer of this handle
     bool use_graph = true;                 // FLOWSE_NO_GRAPH=1: always launch eagerly
     // single-module handles (flowse_block_create): one ResnetBlockBigGANpp / AttnBlockpp / Combine behind the same
@@ -667,6 +670,10 @@ struct Builder {
         const int64_t wino_off = (!in16 && taps == 9 && !cin4 && wino_it != M->wino_of.end() &&
                                   conv_supports_wino(Bn, H, Wd, C1, C2, Cout, taps)) ? wino_it->second : -1;
         const size_t part_off = ks > 1 ? arena.alloc((size_t)ks * Bn * H * Wd * Cout * sizeof(float)) : 0;
+        // split-K: reduce inside the launch (last-arriving slice, ConvArgs::sk_ticket) unless switched off
+        const int64_t sk_tiles = (((int64_t)Bn * H * Wd + 127) / 128) * ((Cout + 31) / 32);
+        const bool sk_in_launch = ks > 1 && conv_splitk_in_launch() && sk_tiles <= SK_TICKETS;
+        const int sk_group = st_nblk > 0 ? H * Wd / st_nblk : 0;
         const size_t table_off = M_table_off;     // by value: the Builder dies before the plan runs
         const std::string full_label = label + "@" + std::to_string(H) + "x" + std::to_string(Wd) + ":" +
                                        std::to_string(C1 + C2) + ">" + std::to_string(Cout);
@@ -687,6 +694,10 @@ struct Builder {
             c.scale = scale;
             c.ksplit = ks;
             c.partial = ks > 1 ? M->A(part_off) : nullptr;
+            if (sk_in_launch) {
+                c.sk_ticket = M->d_ticket;
+                c.sk_group = sk_group;
+            }
             c.stats = st_nblk > 0 ? M->A(st_off) : nullptr;
             c.stats_nblk = st_nblk;
             if (has_gin) {
@@ -717,9 +728,9 @@ struct Builder {
         op(full_label, [=](hipStream_t s) {
             const ConvArgs c = make_args();
             return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s, false);
-        }, flops, in_bytes + (ks > 1 ? part_bytes : out_bytes), has_gin && Cout > 64 && ks == 1,
+        }, flops, in_bytes + (ks > 1 ? part_bytes + (sk_in_launch ? part_bytes + out_bytes : 0.0) : out_bytes), has_gin && Cout > 64 && ks == 1,
            wino_off >= 0 ? flops * (conv_wino_default_f43() ? 0.5 : 2.0 / 3.0) : (use_bf16 && terms == 3) ? 3.0 * flops : flops);
-        if (ks > 1)
+        if (ks > 1 && !sk_in_launch)
             op("splitk_reduce@" + std::to_string(H) + "x" + std::to_string(Wd), [=](hipStream_t s) { return launch_splitk_reduce(make_args(), s); }, 0.0,
                part_bytes + out_bytes);
         if (ks > 1) arena.release(part_off);
@@ -1061,6 +1072,23 @@ static int run_plan(flowse_model* m, Plan* p, hipStream_t s) {
             if (rc != OK) return rc;
             FLOWSE_HIP(hipEventRecord(pd.a, s));
         }
+#ifdef FLOWSE_TS
+        {   // measurement build only: FLOWSE_SKIP_OPS=prefix[,prefix...] drops launches by label (timing what-ifs)
+            static const char* skip = getenv("FLOWSE_SKIP_OPS");
+            bool drop = false;
+            if (skip) {
+                const std::string all(skip);
+                size_t a = 0;
+                while (a <= all.size()) {
+                    size_t b = all.find(',', a);
+                    if (b == std::string::npos) b = all.size();
+                    if (b > a && p->labels[i].compare(0, b - a, all, a, b - a) == 0) drop = true;
+                    a = b + 1;
+                }
+            }
+            if (drop) continue;
+        }
+#endif
         const int rc = p->ops[i](s);
         if (rc != OK) return rc;
         if (prof) {
@@ -1180,6 +1208,8 @@ static void free_device_state(flowse_model* m) {
     if (m->d_w16) (void)hipFree(m->d_w16);
     if (m->d_wino) (void)hipFree(m->d_wino);
     if (m->d_call) (void)hipFree(m->d_call);
+    if (m->d_ticket) (void)hipFree(m->d_ticket);
+    m->d_ticket = nullptr;
     for (hipEvent_t e : m->prof_pool) (void)hipEventDestroy(e);
     m->prof_pool.clear();
     m->prof_used = 0;
@@ -1350,6 +1380,10 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
     FLOWSE_HIP(hipDeviceSynchronize());
     clear_plans(m);          // closures captured weight offsets of the previous packing
     if (!m->d_call) FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_call), sizeof(CallBlock)));
+    if (!m->d_ticket) {
+        FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_ticket), SK_TICKETS * sizeof(unsigned)));
+        FLOWSE_HIP(hipMemset(m->d_ticket, 0, SK_TICKETS * sizeof(unsigned)));
+    }
     if (m->d_w && m->d_w_numel < (int64_t)pk.host.size()) {
         FLOWSE_HIP(hipFree(m->d_w));
         m->d_w = nullptr;
