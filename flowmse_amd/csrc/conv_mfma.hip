@@ -2676,8 +2676,10 @@ static int launch_halo16(const ConvArgs& a, hipStream_t s) {
     const size_t lds_stage = (size_t)(mt2 ? 18 : 10) * (18 * 80 + 96) + (size_t)2 * 128 * 80;
     const size_t lds_epi = ((size_t)128 * 68 + 4 * 64 * 2) * sizeof(float);
     size_t lds = (a.in_dt == DT_F32 && lds_epi > lds_stage) ? lds_epi : lds_stage;      // the staged epilogue is the fp32-storage one
+#ifdef FLOWSE_TS
     static const size_t lds_min = getenv("FLOWSE_HALO16_LDS") ? (size_t)atoi(getenv("FLOWSE_HALO16_LDS")) : 0;   // occupancy probe
     if (lds < lds_min) lds = lds_min;
+#endif
 #define FLOWSE_LH16(GNF, IT, OT, MTV)                                                                             \
     {                                                                                                             \
         if (const int rc = allow_lds<&conv3x3_halo16_kernel<GNF, F16, IT, OT, MTV>>(lds)) return rc;              \
