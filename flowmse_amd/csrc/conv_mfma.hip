@@ -1705,9 +1705,10 @@ static int launch_head4(const ConvArgs& a, hipStream_t s) {
 // error of the 1-D F(4,3) form is ~3x the direct sum's (6e-7 vs 2e-7 rel-L2 on unit-variance data).
 constexpr int F43_HROW = 18 * LDS_ROW + 8;    // words per halo pixel row: 4 rows = 0 mod 64 banks (quad 1 vs quad 0)
 
-template <int GN, int CH, bool SPLIT>
+template <int GN, int CH, bool SPLIT, int TN>
 __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem) {
-    constexpr int BN = 64;
+    static_assert(TN == 1 || !SPLIT, "the sliced form keeps the 64-channel block");
+    constexpr int BN = 64 * TN;                          // TN 32-channel tiles per wave, two channel groups (wn) per block
     constexpr int HROWS = 180;                           // 10 x 18 halo pixels
     constexpr int H_LOADS = 6;
     constexpr int HBUF = 10 * F43_HROW;                  // floats per halo buffer
@@ -1808,14 +1809,16 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     // split-K: gridDim.y slices of consecutive chunks; each slice leaves a raw partial tile (the epilogue's split form)
     const int per_slice = (nchunks + (int)gridDim.y - 1) / (int)gridDim.y;
     const int c_begin = (int)blockIdx.y * per_slice, c_end = min(nchunks, c_begin + per_slice);
-    const unsigned wslice = (unsigned)((n0 >> 5) + wn) * 3u * (unsigned)nchunks;     // in 24 KB units
+    const unsigned wslice = (unsigned)((n0 >> 5) + wn * TN) * 3u * (unsigned)nchunks;    // in 24 KB units; tile j adds 3 nchunks
     const unsigned wvo = (unsigned)lane * 16u + (unsigned)CH * 3u * 4096u;
 
-    f32x16 acc[3];                                       // this wave's three Winograd components
+    f32x16 acc[3][TN];                                   // this wave's three Winograd components x TN channel tiles
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
 
     {   // first chunk: all six quads at once (the accumulators are not live yet)
         u32x4 t[H_LOADS];
@@ -1839,11 +1842,13 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     }
 #define FLOWSE_WLOADB(KX, J, CHK, BF)                                                                                \
     {                                                                                                                \
-        const unsigned so = (wslice + (unsigned)(KX) * (unsigned)nchunks + (unsigned)(CHK)) * 24576u;                \
-        _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                              \
-            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, wvo + (c * 4 + (J)) * 1024, so, 0);         \
-            BF[c] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z),                   \
-                                __uint_as_float(t.w));                                                               \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                             \
+            const unsigned so = (wslice + (unsigned)(3 * j + (KX)) * (unsigned)nchunks + (unsigned)(CHK)) * 24576u;  \
+            _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                          \
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, wvo + (c * 4 + (J)) * 1024, so, 0);     \
+                BF[c][j] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z),            \
+                                       __uint_as_float(t.w));                                                        \
+            }                                                                                                        \
         }                                                                                                            \
     }
 #define FLOWSE_F4(OP) { OP(x) OP(y) OP(z) OP(w) }
@@ -1880,8 +1885,8 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     }
     // operands: CH 0 -> D[0], D[1], D[2] = v0, v1, v2;  CH 1 -> D[4], D[1], D[2] = v5, v3, v4
 #define FLOWSE_WMMA3(V, BF, K)                                                                                       \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                    \
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[(c == 0 && CH == 1) ? 4 : c].K, BF[c].K, acc[c], 0, 0, 0);
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
+        acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[(c == 0 && CH == 1) ? 4 : c].K, BF[c][j].K, acc[c][j], 0, 0, 0);
     // One k-block: request the next block's operands (halo rows from LDS, weights from L2), run this block's 12
     // MFMAs with the next block's transform (and one staged halo quad) fenced in between
 #define FLOWSE_WPHASE(V, BF, NKX, NJ, NCHK, DN, BFN, XQ)                                                             \
@@ -1892,7 +1897,7 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     FLOWSE_WXA(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, z) FLOWSE_FENCE                                                  \
     FLOWSE_WXB(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, w) FLOWSE_FENCE
 
-    float4 dA[5], dB[5], bA[3], bB[3];
+    float4 dA[5], dB[5], bA[3][TN], bB[3][TN];
     {
         const int chunk = c_begin;
         (void)chunk;
@@ -1938,29 +1943,35 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
 
     // This wave's half of A^T m, laid out like four 32-pixel tiles of the <2,2,2,1> epilogue: accumulator register
     // r holds quad row (r&3) + 8*(r>>2) + 4*kh, i.e. row quad r >> 3; output row 4*quad + o is tile row pair
-    // 2*quad + (o >> 1), second row of the pair when o is odd -> tile-row index i = 2*(r>>3) + (o>>1), r' = (r&7) + 8*(o&1)
-    auto scatter = [&](float* Cs, int CROW) {
-        float* Cw = Cs + wn * 32 + li;
+    // 2*quad + (o >> 1), second row of the pair when o is odd -> tile-row index i = 2*(r>>3) + (o>>1), r' = (r&7) + 8*(o&1).
+    // The C tile holds 64 channels: with TN = 1 the two channel groups (wn) side by side; with TN = 2 the 64 channels of
+    // the group `half` (its two 32-channel tiles side by side), the other group's waves only keep the barrier.
+    auto scatter_half = [&](float* Cs, int CROW, int half) {
+        const bool mine = TN == 1 || wn == half;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
-            if (pass == CH) {
+            if (pass == CH && mine) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float o[4];
-                    if (CH == 0) {
-                        const float s12 = acc[1][r] + acc[2][r], d12 = acc[1][r] - acc[2][r];
-                        o[0] = acc[0][r] + s12; o[1] = d12; o[2] = s12; o[3] = d12;
-                    } else {       // acc[0] = m5, acc[1] = m3, acc[2] = m4
-                        const float s34 = acc[1][r] + acc[2][r], d34 = acc[1][r] - acc[2][r];
-                        o[0] = s34; o[1] = 2.f * d34; o[2] = 4.f * s34; o[3] = fmaf(8.f, d34, acc[0][r]);
-                    }
+                for (int j = 0; j < TN; ++j) {
+                    float* Cw = Cs + (TN == 1 ? wn * 32 : j * 32) + li;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        // tile row of (quad r>>3, output row k, column bits of r)
-                        const int row = (2 * (r >> 3) + (k >> 1)) * 32 + ((r & 7) + 8 * (k & 1) & 3) +
-                                        8 * (((r & 7) + 8 * (k & 1)) >> 2) + 4 * kh;
-                        if (pass == 0) Cw[row * CROW] = o[k];
-                        else Cw[row * CROW] += o[k];
+                    for (int r = 0; r < 16; ++r) {
+                        float o[4];
+                        if (CH == 0) {
+                            const float s12 = acc[1][j][r] + acc[2][j][r], d12 = acc[1][j][r] - acc[2][j][r];
+                            o[0] = acc[0][j][r] + s12; o[1] = d12; o[2] = s12; o[3] = d12;
+                        } else {       // acc[0] = m5, acc[1] = m3, acc[2] = m4
+                            const float s34 = acc[1][j][r] + acc[2][j][r], d34 = acc[1][j][r] - acc[2][j][r];
+                            o[0] = s34; o[1] = 2.f * d34; o[2] = 4.f * s34; o[3] = fmaf(8.f, d34, acc[0][j][r]);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            // tile row of (quad r>>3, output row k, column bits of r)
+                            const int row = (2 * (r >> 3) + (k >> 1)) * 32 + ((r & 7) + 8 * (k & 1) & 3) +
+                                            8 * (((r & 7) + 8 * (k & 1)) >> 2) + 4 * kh;
+                            if (pass == 0) Cw[row * CROW] = o[k];
+                            else Cw[row * CROW] += o[k];
+                        }
                     }
                 }
             }
@@ -1968,25 +1979,34 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
         }
     };
     if constexpr (SPLIT) {                               // split slices: raw partial tiles through the shared epilogue
-        conv_epilogue_with<2, 2, 2, 1>(a, smem, m_tl, n0, M, HW, (int)blockIdx.y, W, scatter);
+        conv_epilogue_with<2, 2, 2, 1>(a, smem, m_tl, n0, M, HW, (int)blockIdx.y, W,
+                                       [&](float* Cs, int CROW) { scatter_half(Cs, CROW, 0); });
     } else {
         constexpr int CROW = 68;
-        scatter(smem, CROW);
-        __syncthreads();
         const int bsmp = m_tl / HW;
         const int rem = m_tl - bsmp * HW;
-        tile128x64_out<float>(a, smem, CROW, smem + 128 * CROW, m_tl, W, n0, bsmp,
-                              ((rem / W) >> 3) * (W >> 4) + ((rem % W) >> 4));
+        const int tile = ((rem / W) >> 3) * (W >> 4) + ((rem % W) >> 4);
+#pragma unroll 1
+        for (int half = 0; half < TN; ++half) {
+            if (half) __syncthreads();                   // the output stage of the first half has left the C tile
+            scatter_half(smem, CROW, half);
+            __syncthreads();
+            tile128x64_out<float>(a, smem, CROW, smem + 128 * CROW, m_tl, W, n0 + half * 64, bsmp, tile);
+        }
     }
 }
 
 // SPLIT: the launch is sliced over chunks (gridDim.y > 1) and every block leaves a raw partial tile
-template <int GN, bool SPLIT = false>
-__global__ __launch_bounds__(256, 3) void conv3x3_f43_kernel(ConvArgs a) {
+// TN = 1: 64 output channels per block, three blocks per CU.  TN = 2: 128 channels per block (each wave two 32-channel
+// tiles), two blocks per CU: every transformed input fragment, every staged (GroupNorm + SiLU) halo element and every LDS
+// read feeds twice the MFMAs -- the VALU work per MFMA, which is what holds the matrix pipe below 0.75 in the TN = 1 form
+// (three waves of a SIMD issue ~2 VALU per 64-cycle MFMA), halves.
+template <int GN, bool SPLIT = false, int TN = 1>
+__global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv3x3_f43_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // waves 0,1: component half 0; waves 2,3: half 1.  Both bodies execute the same barriers.
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7)) conv3x3_f43_body<GN, 1, SPLIT>(a, smem);
-    else conv3x3_f43_body<GN, 0, SPLIT>(a, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7)) conv3x3_f43_body<GN, 1, SPLIT, TN>(a, smem);
+    else conv3x3_f43_body<GN, 0, SPLIT, TN>(a, smem);
 }
 
 // [Cout][9][Cin] -> fragment order [Cout/32][kx][Cin/32][component 0..5][k-block j][lane][4]; stored component order:
@@ -2027,19 +2047,25 @@ int launch_f43_weights(const float* w_packed, int Cout, int Cin, float* out, hip
 
 static int launch_f43(const ConvArgs& a, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
-    const int grid = (int)(M / 128) * (a.Cout / 64);
     const int ks = a.ksplit > 1 ? a.ksplit : 1;       // slices of 32-channel chunks (gridDim.y), see wino_plan
+    // 128-channel blocks (two per CU) when the layer allows it and two rounds of 512 blocks remain; FLOWSE_F43_BN64=1
+    // keeps the 64-channel form everywhere (A-B hook)
+    static const bool bn64 = getenv("FLOWSE_F43_BN64") != nullptr;
+    const bool wide = !bn64 && !a.partial && (a.Cout % 128) == 0 && (M / 128) * (a.Cout / 128) >= 1024;
+    const int grid = (int)(M / 128) * (a.Cout / (wide ? 128 : 64));
     const size_t lds = 2 * 10 * F43_HROW * sizeof(float);              // two halo buffers; > the epilogue's C tile
     const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;
-#define FLOWSE_LF43(G, SP)                                                                                   \
+#define FLOWSE_LF43(G, SP, TNV)                                                                              \
     {                                                                                                        \
-        if (const int rc = allow_lds<&conv3x3_f43_kernel<G, SP>>(lds)) return rc;                            \
-        hipLaunchKernelGGL((conv3x3_f43_kernel<G, SP>), dim3(grid, ks), dim3(256), lds, s, a);               \
+        if (const int rc = allow_lds<&conv3x3_f43_kernel<G, SP, TNV>>(lds)) return rc;                       \
+        hipLaunchKernelGGL((conv3x3_f43_kernel<G, SP, TNV>), dim3(grid, ks), dim3(256), lds, s, a);          \
     }
     if (a.partial) {
-        if (gn == 2) FLOWSE_LF43(2, true) else if (gn == 1) FLOWSE_LF43(1, true) else FLOWSE_LF43(0, true)
+        if (gn == 2) FLOWSE_LF43(2, true, 1) else if (gn == 1) FLOWSE_LF43(1, true, 1) else FLOWSE_LF43(0, true, 1)
+    } else if (wide) {
+        if (gn == 2) FLOWSE_LF43(2, false, 2) else if (gn == 1) FLOWSE_LF43(1, false, 2) else FLOWSE_LF43(0, false, 2)
     } else {
-        if (gn == 2) FLOWSE_LF43(2, false) else if (gn == 1) FLOWSE_LF43(1, false) else FLOWSE_LF43(0, false)
+        if (gn == 2) FLOWSE_LF43(2, false, 1) else if (gn == 1) FLOWSE_LF43(1, false, 1) else FLOWSE_LF43(0, false, 1)
     }
 #undef FLOWSE_LF43
     FLOWSE_LAUNCH_CHECK();
