@@ -269,8 +269,8 @@ def main():
             form = None
             if args.precision == "fp32" and not os.environ.get("FLOWSE_NO_WINOGRAD"):
                 form = "F(2,3)" if os.environ.get("FLOWSE_WINOGRAD") == "f23" else "F(4,3)"
-            kname = ({"F(4,3)": "flowse::conv3x3_f43_kernel<2, false>", "F(2,3)": "flowse::conv3x3_wino_kernel<2>"}[form] +
-                     f" (fp32 {form}-Winograd implicit-GEMM 3x3 conv, 8x16 pixel x 64 channel tile, LDS halo, fused "
+            kname = ({"F(4,3)": "flowse::conv3x3_f43_kernel<2, false, 2>", "F(2,3)": "flowse::conv3x3_wino_kernel<2>"}[form] +
+                     f" (fp32 {form}-Winograd implicit-GEMM 3x3 conv, 8x16 pixel x 128 channel block, LDS halo, fused "
                      "GroupNorm+SiLU input, weights streamed from L2 in MFMA fragment order)" if form else
                      "flowse::conv3x3_halo_kernel<2,2,2,2,2> (fp32 implicit-GEMM 3x3 conv, 128x128 tile, LDS halo, "
                      "fused GroupNorm+SiLU input)" if args.precision == "fp32" else

@@ -2045,13 +2045,17 @@ int launch_f43_weights(const float* w_packed, int Cout, int Cin, float* out, hip
     return OK;
 }
 
+// 128-channel blocks (two per CU) when the layer allows it and at least one full round of 512 such blocks exists
+// (measured: 512 beats 1024 and 256 at B = 1 and B = 8); FLOWSE_F43_BN64=1 keeps the 64-channel form everywhere (A-B hook)
+bool conv_f43_wide(int B, int H, int W, int Cout) {
+    static const bool bn64 = getenv("FLOWSE_F43_BN64") != nullptr;
+    return !bn64 && (Cout % 128) == 0 && ((int64_t)B * H * W / 128) * (Cout / 128) >= 512;
+}
+
 static int launch_f43(const ConvArgs& a, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int ks = a.ksplit > 1 ? a.ksplit : 1;       // slices of 32-channel chunks (gridDim.y), see wino_plan
-    // 128-channel blocks (two per CU) when the layer allows it and two rounds of 512 blocks remain; FLOWSE_F43_BN64=1
-    // keeps the 64-channel form everywhere (A-B hook)
-    static const bool bn64 = getenv("FLOWSE_F43_BN64") != nullptr;
-    const bool wide = !bn64 && !a.partial && (a.Cout % 128) == 0 && (M / 128) * (a.Cout / 128) >= 1024;
+    const bool wide = !a.partial && conv_f43_wide(a.B, a.H, a.W, a.Cout);
     const int grid = (int)(M / 128) * (a.Cout / (wide ? 128 : 64));
     const size_t lds = 2 * 10 * F43_HROW * sizeof(float);              // two halo buffers; > the epilogue's C tile
     const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;

@@ -124,7 +124,7 @@ struct Plan {
     std::vector<double> flops, bytes;      // algorithmic work / HBM traffic of each launch
     std::vector<double> issued;            // FLOPs the matrix cores execute for it (Winograd forms: 1/2 or 2/3 of `flops`)
     std::vector<char> dominant;            // 1 = a launch of the dominant kernel: the unsplit 3x3 ResBlock conv with fused
-                                           // GroupNorm+SiLU input (conv3x3_f43_kernel<2, false> in the fp32 mode)
+                                           // GroupNorm+SiLU input (conv3x3_f43_kernel<2, false, 2> in the fp32 mode)
     // The launch list holds no per-call argument (those live in the handle's device-resident CallBlock), so after one
     // eager pass it is captured as a hipGraph and replayed: one graph launch per network evaluation.
     int eager_runs = 0;
@@ -728,7 +728,8 @@ struct Builder {
         op(full_label, [=](hipStream_t s) {
             const ConvArgs c = make_args();
             return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s, false);
-        }, flops, in_bytes + (ks > 1 ? part_bytes + (sk_in_launch ? part_bytes + out_bytes : 0.0) : out_bytes), has_gin && Cout > 64 && ks == 1,
+        }, flops, in_bytes + (ks > 1 ? part_bytes + (sk_in_launch ? part_bytes + out_bytes : 0.0) : out_bytes),
+           has_gin && Cout > 64 && ks == 1 && (wino_off < 0 || !conv_wino_default_f43() || conv_f43_wide(Bn, H, Wd, Cout)),
            wino_off >= 0 ? flops * (conv_wino_default_f43() ? 0.5 : 2.0 / 3.0) : (use_bf16 && terms == 3) ? 3.0 * flops : flops);
         if (ks > 1 && !sk_in_launch)
             op("splitk_reduce@" + std::to_string(H) + "x" + std::to_string(Wd), [=](hipStream_t s) { return launch_splitk_reduce(make_args(), s); }, 0.0,

@@ -150,6 +150,8 @@ WINO_CASES = [
     (2, 72, 256, 64, 32, 128, True, True, 1.0, True),           # H = 9 tiles (odd), 64+32 concat, strip-major walk
     (8, 16, 16, 256, 0, 256, True, True, 0.70710678, True),     # 64 blocks: F(4,3) split over 4 slices of chunks
     (1, 64, 64, 256, 256, 256, True, False, 1.0, True),         # single utterance: 128 blocks, split 4 x 4 chunks
+    (8, 64, 128, 128, 0, 128, True, True, 0.70710678, True),    # 512 blocks of 128 channels: the F(4,3) 128-channel block form
+    (2, 128, 128, 128, 128, 256, True, True, 1.0, True),        # same form, two channel blocks, concat input
 ]
 
 
