@@ -1688,6 +1688,25 @@ static int launch_head4(const ConvArgs& a, hipStream_t s) {
     return OK;
 }
 
+#ifdef FLOWSE_TS
+// Measurement build only (-DFLOWSE_TS): per-block phase timestamps of the F(4,3) and 16-bit halo kernels (s_memtime) + HW ids.
+__device__ unsigned long long g_ts[8192 * 10];
+extern "C" int flowse_debug_ts(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ts), (size_t)n * 8) == hipSuccess ? 0 : 1;
+}
+#define FLOWSE_TS_MARK(k) if (ts_on) ts[k] = __builtin_amdgcn_s_memtime();
+// phase marks inside taps 2..7 of chunk 1: ts[k] accumulates the time since the previous mark
+#define FLOWSE_TS_TAP(k)                                                  \
+    if (ts_on && chunk == 1 && tap >= 2 && tap <= 7) {                    \
+        const unsigned long long now = __builtin_amdgcn_s_memtime();      \
+        if (k >= 2) ts[k] += now - ts_last;                               \
+        ts_last = now;                                                    \
+    }
+#else
+#define FLOWSE_TS_MARK(k)
+#define FLOWSE_TS_TAP(k)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // F(4,3) Winograd variant (same tile, same halo staging, same fragment-order weight stream as the F(2,3) kernel).
 //
@@ -1713,6 +1732,12 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     constexpr int H_LOADS = 6;
     constexpr int HBUF = 10 * F43_HROW;                  // floats per halo buffer
     float* Hs = smem;                                    // [2][10][F43_HROW]
+#ifdef FLOWSE_TS
+    unsigned long long ts[10];
+    const bool ts_on = a.H == 256 && a.C1 + a.C2 == 128 && GN == 2 && !SPLIT;
+    for (int k = 0; k < 10; ++k) ts[k] = 0;
+#endif
+    FLOWSE_TS_MARK(0)
 
     const int tid = threadIdx.x;
     const int H = a.H, W = a.W, HW = H * W;
@@ -1832,6 +1857,7 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
         }
     }
     __syncthreads();
+    FLOWSE_TS_MARK(1)
 
 #define FLOWSE_FENCE __builtin_amdgcn_sched_barrier(0);
     // five halo rows of k-block (KX, J) from LDS; three weight components of k-block (KX, J) of chunk CHK from L2
@@ -1940,20 +1966,22 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
 #undef FLOWSE_WMMA3
 #undef FLOWSE_WPHASE
 #undef FLOWSE_FENCE
+    FLOWSE_TS_MARK(6)
 
     // This wave's half of A^T m, laid out like four 32-pixel tiles of the <2,2,2,1> epilogue: accumulator register
     // r holds quad row (r&3) + 8*(r>>2) + 4*kh, i.e. row quad r >> 3; output row 4*quad + o is tile row pair
     // 2*quad + (o >> 1), second row of the pair when o is odd -> tile-row index i = 2*(r>>3) + (o>>1), r' = (r&7) + 8*(o&1).
-    // The C tile holds 64 channels: with TN = 1 the two channel groups (wn) side by side; with TN = 2 the 64 channels of
-    // the group `half` (its two 32-channel tiles side by side), the other group's waves only keep the barrier.
+    // half >= 0: the C tile holds 64 channels -- with TN = 1 the two channel groups (wn) side by side; with TN = 2 the
+    // 64 channels of the group `half`, the other group's waves only keep the barrier.  half < 0 (TN = 2): the tile holds
+    // all 128 channels and both groups scatter at once.
     auto scatter_half = [&](float* Cs, int CROW, int half) {
-        const bool mine = TN == 1 || wn == half;
+        const bool mine = TN == 1 || half < 0 || wn == half;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == CH && mine) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    float* Cw = Cs + (TN == 1 ? wn * 32 : j * 32) + li;
+                    float* Cw = Cs + (TN == 1 ? wn * 32 : half < 0 ? wn * 64 + j * 32 : j * 32) + li;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float o[4];
@@ -1982,18 +2010,40 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
         conv_epilogue_with<2, 2, 2, 1>(a, smem, m_tl, n0, M, HW, (int)blockIdx.y, W,
                                        [&](float* Cs, int CROW) { scatter_half(Cs, CROW, 0); });
     } else {
-        constexpr int CROW = 68;
+        // C tile of all 64 TN channels ([128][64 TN + 4] floats): with TN = 2 both channel groups scatter at once (two
+        // waves per pass instead of one), then the output stage runs over the two 64-channel halves back to back
+        constexpr int CROW = 64 * TN + 4;
         const int bsmp = m_tl / HW;
         const int rem = m_tl - bsmp * HW;
         const int tile = ((rem / W) >> 3) * (W >> 4) + ((rem % W) >> 4);
+        scatter_half(smem, CROW, -1);
+        __syncthreads();
+#ifdef FLOWSE_TS
+        if (ts_on) ts[2] = __builtin_amdgcn_s_memtime();
+#endif
+        float* red = smem + 128 * CROW;
 #pragma unroll 1
         for (int half = 0; half < TN; ++half) {
-            if (half) __syncthreads();                   // the output stage of the first half has left the C tile
-            scatter_half(smem, CROW, half);
-            __syncthreads();
-            tile128x64_out<float>(a, smem, CROW, smem + 128 * CROW, m_tl, W, n0 + half * 64, bsmp, tile);
+            if (half) __syncthreads();                   // the statistics scratch of the first half has been read
+            tile128x64_out<float>(a, smem + half * 64, CROW, red, m_tl, W, n0 + half * 64, bsmp, tile);
+#ifdef FLOWSE_TS
+            if (ts_on && half == 0) ts[3] = ts[4] = __builtin_amdgcn_s_memtime();
+#endif
         }
     }
+#ifdef FLOWSE_TS
+    if (ts_on) {
+        __syncthreads();
+        if (CH == 0) {
+            ts[7] = __builtin_amdgcn_s_memtime();
+            ts[8] = __builtin_amdgcn_s_getreg(63492);          // HW_ID
+            ts[9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+            ts[5] = blockIdx.x;
+            if (tid == 0 && bid < 8192)
+                for (int k = 0; k < 10; ++k) g_ts[bid * 10 + k] = ts[k];
+        }
+    }
+#endif
 }
 
 // SPLIT: the launch is sliced over chunks (gridDim.y > 1) and every block leaves a raw partial tile
@@ -2057,7 +2107,9 @@ static int launch_f43(const ConvArgs& a, hipStream_t s) {
     const int ks = a.ksplit > 1 ? a.ksplit : 1;       // slices of 32-channel chunks (gridDim.y), see wino_plan
     const bool wide = !a.partial && conv_f43_wide(a.B, a.H, a.W, a.Cout);
     const int grid = (int)(M / 128) * (a.Cout / (wide ? 128 : 64));
-    const size_t lds = 2 * 10 * F43_HROW * sizeof(float);              // two halo buffers; > the epilogue's C tile
+    const size_t lds_halo = 2 * 10 * F43_HROW * sizeof(float);         // two halo buffers; > the 64-channel C tile
+    const size_t lds_c = ((size_t)128 * (64 * 2 + 4) + 4 * 64 * 2) * sizeof(float);   // the 128-channel C tile + statistics scratch
+    const size_t lds = wide && lds_c > lds_halo ? lds_c : lds_halo;
     const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;
 #define FLOWSE_LF43(G, SP, TNV)                                                                              \
     {                                                                                                        \
@@ -2386,24 +2438,6 @@ __device__ __forceinline__ u32x4 widen_quad(typename RawQuad<ST>::type t) {
     }
 }
 
-#ifdef FLOWSE_TS
-// Measurement build only (-DFLOWSE_TS): per-block phase timestamps of the 16-bit halo kernel (s_memtime) + HW ids.
-__device__ unsigned long long g_ts[8192 * 10];
-extern "C" int flowse_debug_ts(unsigned long long* host, int n) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ts), (size_t)n * 8) == hipSuccess ? 0 : 1;
-}
-#define FLOWSE_TS_MARK(k) if (ts_on) ts[k] = __builtin_amdgcn_s_memtime();
-// phase marks inside taps 2..7 of chunk 1: ts[k] accumulates the time since the previous mark
-#define FLOWSE_TS_TAP(k)                                                  \
-    if (ts_on && chunk == 1 && tap >= 2 && tap <= 7) {                    \
-        const unsigned long long now = __builtin_amdgcn_s_memtime();      \
-        if (k >= 2) ts[k] += now - ts_last;                               \
-        ts_last = now;                                                    \
-    }
-#else
-#define FLOWSE_TS_MARK(k)
-#define FLOWSE_TS_TAP(k)
-#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Single-plane (bf16 / half) LDS-halo 3x3 kernel, built for THREE blocks per CU.

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 if __name__ == "__main__":
-    sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--precision", "bf16", "--no-cpu-baseline", "--no-alt"]
+    sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--precision", os.environ.get("TS_PRECISION", "bf16"),
+                "--no-cpu-baseline", "--no-alt"]     # TS_PRECISION=fp32: the F(4,3) kernel's marks (no per-tap marks there)
     os.environ["FLOWSE_NO_GRAPH"] = "1"
     import bench
     bench.main()
@@ -38,6 +39,10 @@ if __name__ == "__main__":
     for k, n in enumerate(names):
         v = ph[:, k]
         print(f"{n:14s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}  p90 {np.percentile(v, 90):9.0f}")
+    if os.environ.get("TS_PRECISION") == "fp32":        # F(4,3) kernel: slots 2..5 = epilogue marks (scatter / output stage per half)
+        e = np.stack([t[:, 2] - t[:, 6], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3], t[:, 7] - t[:, 4]], 1)
+        for k, n in enumerate(["epi:scatter0", "epi:out0", "epi:scatter1", "epi:out1"]):
+            print(f"{n:14s} mean {e[:, k].mean():9.0f}  p50 {np.percentile(e[:, k], 50):9.0f}")
     hw = t[:, 8]
     cu = (hw >> 8) & 0xF
     sh = (hw >> 12) & 0x1
@@ -51,7 +56,7 @@ if __name__ == "__main__":
         rows = rows[np.argsort(rows[:, 0])]
         print(f"CU key {kk}: {len(rows)} blocks")
         for r in rows[:8]:
-            print("   start %8d  pro %6d  main %6d  epi %6d  end %8d" % (r[0] - t0, r[1] - r[0], r[6] - r[1], r[7] - r[6], r[7] - t0))
+            print("   start %8d  pro %6d  main %6d  epi %6d  end %8d  blockIdx.x %d" % (r[0] - t0, r[1] - r[0], r[6] - r[1], r[7] - r[6], r[7] - t0, r[5]))
     busy = []
     for kk in np.unique(key):
         rows = t[key == kk]
