@@ -17,13 +17,16 @@
 //
 // Kernels in this file (dispatch: launch_conv / launch_conv_cin4):
 //   conv3x3_f43_kernel         3x3, H % 8 == 0, W % 16 == 0, Cin % 32 == 0, Cout % 64 == 0, >= 256 blocks: F(4,3)
-//                              Winograd along the vertical axis; 8x16-pixel x 64-channel tile, 3 blocks per CU; the
-//                              input halo of a 32-channel chunk double-buffered in LDS (optional fused GroupNorm+SiLU
-//                              on the way in), transformed weights fetched from L2 in MFMA fragment order.  The
-//                              production kernel (~70 % of GPU time).  conv3x3_wino_kernel: the F(2,3) form.
+//                              Winograd along the vertical axis; 8x16-pixel tile x 128 channels (2 blocks per CU, layers
+//                              with >= 512 such blocks) or x 64 channels (3 blocks per CU); the input halo of a
+//                              32-channel chunk double-buffered in LDS (optional fused GroupNorm+SiLU on the way in),
+//                              transformed weights fetched from L2 in MFMA fragment order.  The production kernel
+//                              (~75 % of GPU time).  conv3x3_wino_kernel: the F(2,3) form.
 //   conv3x3_halo_kernel        the direct form of the same tiling (per-tap weight tile through LDS): narrow heads
 //                              (Cout = 4), FLOWSE_NO_WINOGRAD=1, and the base of
-//   conv3x3_halo_bf16_kernel   the bf16 / bf16x3 / fp16 operand modes (v_mfma_f32_32x32x16_*).
+//   conv3x3_halo_bf16_kernel   the bf16x3 operand mode and small 16-bit launches; conv3x3_halo16_kernel: the 16-bit
+//                              storage modes (v_mfma_f32_32x32x16_*, 8x16 or 16x16 pixel tile x 128 channels, output
+//                              straight from the accumulators); conv_flat16_kernel: their flat 1x1 / small 3x3 form.
 //   conv_mfma_fast_kernel      flat pixel tiling, A gathered per tap through a window buffer descriptor: 1x1 convs
 //                              and 3x3 on small images; split-K (gridDim.y) + splitk_reduce[_stats] for tiny images.
 //   conv_mfma_kernel           generic fallback (any channel count multiple of 4, chunks straddling the concat).
