@@ -269,7 +269,9 @@ def main():
             form = None
             if args.precision == "fp32" and not os.environ.get("FLOWSE_NO_WINOGRAD"):
                 form = "F(2,3)" if os.environ.get("FLOWSE_WINOGRAD") == "f23" else "F(4,3)"
-            kname = ({"F(4,3)": "flowse::conv3x3_f43_kernel<2, false, 2>", "F(2,3)": "flowse::conv3x3_wino_kernel<2>"}[form] +
+            f43_name = ("flowse::conv3x3_f43_kernel<2, false, 1>" if os.environ.get("FLOWSE_F43_BN64")
+                        else "flowse::conv3x3_f43_kernel<2, false, 2>")
+            kname = ({"F(4,3)": f43_name, "F(2,3)": "flowse::conv3x3_wino_kernel<2>"}[form] +
                      f" (fp32 {form}-Winograd implicit-GEMM 3x3 conv, 8x16 pixel x 128 channel block, LDS halo, fused "
                      "GroupNorm+SiLU input, weights streamed from L2 in MFMA fragment order)" if form else
                      "flowse::conv3x3_halo_kernel<2,2,2,2,2> (fp32 implicit-GEMM 3x3 conv, 128x128 tile, LDS halo, "

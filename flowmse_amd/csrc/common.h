@@ -282,6 +282,7 @@ bool conv_wino_default_f43();       // FLOWSE_WINOGRAD=f23 selects the F(2,3) ke
 bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // whole-K F(4,3) launches of this shape use 128-channel blocks (conv3x3_f43_kernel<GN, false, 2>)
 bool conv_f43_wide(int B, int H, int W, int Cout);
+bool conv_f43_forced_bn64();      // FLOWSE_F43_BN64=1: the 64-channel form everywhere (A-B hook)
 // host helper: split fp32 conv weights [Cout][Cin][3][3] into the packed bf16 planes described above
 void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst, bool f16 = false);
 inline int64_t conv_bf16_numel(int Cout, int Cin, int terms) { return (int64_t)Cout * 9 * Cin * (terms == 1 ? 1 : 2); }

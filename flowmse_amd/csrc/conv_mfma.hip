@@ -2100,9 +2100,12 @@ int launch_f43_weights(const float* w_packed, int Cout, int Cin, float* out, hip
 
 // 128-channel blocks (two per CU) when the layer allows it and at least one full round of 512 such blocks exists
 // (measured: 512 beats 1024 and 256 at B = 1 and B = 8); FLOWSE_F43_BN64=1 keeps the 64-channel form everywhere (A-B hook)
-bool conv_f43_wide(int B, int H, int W, int Cout) {
+bool conv_f43_forced_bn64() {
     static const bool bn64 = getenv("FLOWSE_F43_BN64") != nullptr;
-    return !bn64 && (Cout % 128) == 0 && ((int64_t)B * H * W / 128) * (Cout / 128) >= 512;
+    return bn64;
+}
+bool conv_f43_wide(int B, int H, int W, int Cout) {
+    return !conv_f43_forced_bn64() && (Cout % 128) == 0 && ((int64_t)B * H * W / 128) * (Cout / 128) >= 512;
 }
 
 static int launch_f43(const ConvArgs& a, hipStream_t s) {

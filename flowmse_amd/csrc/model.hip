@@ -729,7 +729,8 @@ struct Builder {
             const ConvArgs c = make_args();
             return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s, false);
         }, flops, in_bytes + (ks > 1 ? part_bytes + (sk_in_launch ? part_bytes + out_bytes : 0.0) : out_bytes),
-           has_gin && Cout > 64 && ks == 1 && (wino_off < 0 || !conv_wino_default_f43() || conv_f43_wide(Bn, H, Wd, Cout)),
+           has_gin && Cout > 64 && ks == 1 &&
+               (wino_off < 0 || !conv_wino_default_f43() || conv_f43_forced_bn64() || conv_f43_wide(Bn, H, Wd, Cout)),
            wino_off >= 0 ? flops * (conv_wino_default_f43() ? 0.5 : 2.0 / 3.0) : (use_bf16 && terms == 3) ? 3.0 * flops : flops);
         if (ks > 1 && !sk_in_launch)
             op("splitk_reduce@" + std::to_string(H) + "x" + std::to_string(Wd), [=](hipStream_t s) { return launch_splitk_reduce(make_args(), s); }, 0.0,
