@@ -17,6 +17,13 @@ A run can never silently measure fewer GPUs than asked: N ranks need N visible d
 FLOWSE_BENCH_SHARE_GPU=1 maps every rank to device 0 (then FLOWSE_BENCH_BACKEND=gloo, RCCL cannot share a device).
 
 Metric: enhanced spectrogram-frames/sec at N=5 solver steps (frame = one STFT column of 256 bins).
+
+`--workload vbdmd` runs BASELINE config[3] instead: 824 synthetic utterances of ragged length (T = 64 k, k in 2..10,
+the set SURVEY 8(d) prescribes when the VoiceBank-DEMAND test set is absent) through flowmse_amd.parallel.
+enhance_sharded -- LPT shard over the ranks, equal-length batches, N=5 Euler sampler, ONE final gather to rank 0 --
+the multi-GPU form of the reference's loop over the test set (evaluate.py:97-136).  One "step" = one pass over the
+whole set (total work fixed: "scaling": "strong"); the line carries every rank's frames and times, so load imbalance
+and the serial gather tail are visible.  Runs at --gpus 1 as well.
 """
 import argparse
 import json
@@ -97,6 +104,133 @@ def cpu_baseline(sd, nsolver, frames, reps, budget_s=60.0):
                       f"(the path is linear in batch and steps)"}
 
 
+# BASELINE config[3] stand-in for the VoiceBank-DEMAND test set (824 utterances, public size of that set; the data
+# itself is not available offline): padded frame counts T = 64 k, k = 2..10, skewed towards short
+# utterances like the real set (most files 2-4 s), true lengths uniformly inside the last 64-frame block.
+VBDMD_UTTS = 824
+VBDMD_K_WEIGHTS = {2: 0.16, 3: 0.22, 4: 0.20, 5: 0.14, 6: 0.10, 7: 0.07, 8: 0.05, 9: 0.035, 10: 0.025}
+
+
+def vbdmd_lengths(n):
+    """Deterministic true frame counts of the n synthetic utterances (hash-based, no RNG library)."""
+    from flowmse_amd.util import synth
+    u = synth.uniform01(2024, 3, n)
+    v = synth.uniform01(2024, 4, n)
+    ks, acc, cdf = sorted(VBDMD_K_WEIGHTS), 0.0, []
+    for k in ks:
+        acc += VBDMD_K_WEIGHTS[k]
+        cdf.append(acc)
+    out = []
+    for a, b in zip(u, v):
+        k = next((kk for kk, c in zip(ks, cdf) if a * acc < c), ks[-1])
+        out.append(64 * (k - 1) + 1 + int(b * 64))            # in (64 (k-1), 64 k]
+    return out
+
+
+def run_vbdmd(args, model, dev, world, rank, backend, share):
+    """config[3]: the whole ragged set through enhance_sharded, timed end to end (shard -> batches -> sampler -> gather)."""
+    from flowmse_amd.parallel import enhance_sharded, shard_utterances
+    from flowmse_amd.sampling import get_white_box_solver
+    from flowmse_amd.util import synth
+    n, F, NS = args.utts, 256, args.nsolver
+    true_len = vbdmd_lengths(n)
+    padded = [((t + 63) // 64) * 64 for t in true_len]
+    mine = set(shard_utterances(padded, world)[rank])
+    # every rank holds the lengths of all utterances and the data of its own shard, resident in HBM before timing
+    specs, noise = [], {}
+    for i in range(n):
+        if i in mine:
+            specs.append(torch.from_numpy(synth.synth_spectrogram(i, 1, F, true_len[i]))[0, 0].to(dev))
+            noise[i] = torch.from_numpy(synth.synth_noise(i, 1, F, padded[i])).to(dev)
+        else:
+            specs.append(torch.empty(F, true_len[i], dtype=torch.complex64, device="meta"))
+    ws_bytes = model.dnn.reserve(min(args.batch, n), F, max(padded))
+
+    def sample_fn(Y, ids):
+        Z = torch.cat([noise[i] for i in ids])
+        return get_white_box_solver(args.solver, model.ode, model, Y=Y, Y_prior=Y, T_rev=1.0, t_eps=0.03, N=NS, z=Z)()[0]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_pass(stats):
+        return enhance_sharded(sample_fn, specs, max_batch=args.batch, stats=stats)
+
+    for _ in range(max(args.warmup, 2)):          # every (batch, T) shape: eager pass, then hipGraph capture
+        one_pass({})
+    g0 = model.dnn.graph_launches()
+    barrier()
+    t0 = time.perf_counter()
+    st = {}
+    for _ in range(args.steps):
+        st = {}
+        out = one_pass(st)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    graph_launches = model.dnn.graph_launches() - g0
+    mine_row = [elapsed, st["sample_s"], st["gather_s"], float(st["frames"]), float(st["utterances"]), float(st["batches"])]
+    rows = [mine_row]
+    if world > 1:
+        tt = torch.zeros(world, len(mine_row), dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        tt[rank] = torch.tensor(mine_row, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        rows = tt.tolist()
+        elapsed = max(r[0] for r in rows)
+    if rank != 0:
+        return None
+    assert len(out) == n and all(o is not None and o.shape == (F, t) for o, t in zip(out, true_len)), "gather lost data"
+    checked = not os.environ.get("FLOWSE_BENCH_NO_CHECK")
+    if checked:
+        assert all(bool(torch.isfinite(torch.view_as_real(o)).all()) for o in out), "non-finite output"
+    frames = sum(padded)
+    nfe_per_step = (NS - 1) * {"euler": 1, "heun": 2, "rk4": 4}[args.solver] + 1
+    value = args.steps * frames / elapsed
+    hist = {}
+    for p in padded:
+        hist[p] = hist.get(p, 0) + 1
+    rank_frames = [r[3] for r in rows]
+    return {
+        "metric": f"enhanced spectrogram-frames/sec at N={NS} solver steps",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": DTYPE_NAMES[args.precision], "data": "synthetic",
+        "config": {"workload": f"BASELINE config[3]: {n} synthetic utterances standing in for the VoiceBank-DEMAND test set "
+                               f"(not available offline), ragged [1,1,{F},T] with padded T = 64k, k in 2..10, sharded by "
+                               f"utterance over {world} GPU(s) (LPT by padded length, equal-length batches of <= {args.batch}), "
+                               f"N={NS} {args.solver} steps ({nfe_per_step} NFE), NCSN++ (65.6M params, synthetic weights), "
+                               f"precision mode {args.precision}; one step = one pass over the whole set incl. the final "
+                               "gather to rank 0",
+                   "utterances": n, "frames_padded_total": frames, "frames_true_total": sum(true_len),
+                   "padded_length_histogram": {str(k): hist[k] for k in sorted(hist)},
+                   "max_batch": args.batch, "solver_steps": NS,
+                   "parallelism": f"dp{world} (per-utterance, final gather to rank 0 only)",
+                   "collective_backend": (backend if world > 1 else None),
+                   "ranks_share_one_device": share if world > 1 else False,
+                   "hip_graph_replay": graph_launches > 0, "hip_graph_launches_rank0": graph_launches,
+                   "finite_output_checked": checked,
+                   "workspace_GB": round(ws_bytes / 2 ** 30, 2)},
+        "frames_value_counts": "padded frames (what the kernels process); true (unpadded) frames/s = value * "
+                               f"{sum(true_len) / frames:.4f}",
+        "per_rank": {"frames": rank_frames, "utterances": [r[4] for r in rows], "batches": [r[5] for r in rows],
+                     "ms_per_step": [round(1e3 * r[0] / args.steps, 3) for r in rows],
+                     "last_pass_sampler_ms": [round(1e3 * r[1], 3) for r in rows],
+                     "last_pass_gather_ms": [round(1e3 * r[2], 3) for r in rows],
+                     "frame_imbalance_max_over_mean": max(rank_frames) / (sum(rank_frames) / len(rank_frames))},
+        "achieved_TFLOPs_whole_path": value * nfe_per_step * FLOP_PER_FRAME_NFE / 1e12,
+    }
+
+
+DTYPE_NAMES = {"fp32": "f32",
+               "bf16x3": "f32 (3x3 convs as split-bf16 x3 MFMA, fp32 accumulate)",
+               "bf16": "bf16 activation storage + bf16 matrix-core operands (fp32 accumulate, GroupNorm statistics, "
+                       "4-channel tensors and attention interior)",
+               "fp16": "fp16 activation storage + fp16 matrix-core operands (fp32 accumulate, GroupNorm statistics, "
+                       "4-channel tensors and attention interior)"}
+
+
 def spawn_ranks(n):
     """Re-execute this script as n ranks on this node (one per GPU) and relay rank 0's JSON line."""
     import socket
@@ -129,6 +263,10 @@ def main():
                     help="matrix-core operand mode of the large 3x3 convs (default: exact fp32)")
     ap.add_argument("--no-alt", action="store_true", help="skip the bf16x3 / bf16 operand-mode legs")
     ap.add_argument("--profile-all", action="store_true", help="per-op timing table to stderr (extra untimed pass)")
+    ap.add_argument("--workload", default="config1", choices=["config1", "vbdmd"],
+                    help="config1: BASELINE config[1] (one [batch,1,256,frames] batch per GPU, weak scaling; the default); "
+                         "vbdmd: BASELINE config[3] (ragged utterance set sharded over the GPUs, strong scaling)")
+    ap.add_argument("--utts", type=int, default=VBDMD_UTTS, help="--workload vbdmd: number of utterances")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:         # plain `python bench.py --gpus N`: spawn the ranks
@@ -177,6 +315,14 @@ def main():
     model = model.to(dev).eval()
     model.dnn.set_precision(args.precision)
 
+    if args.workload == "vbdmd":
+        out = run_vbdmd(args, model, dev, world, rank, backend, share)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     B, F, T, NS = args.batch, 256, args.frames, args.nsolver
     # this rank's batch: utterance indices rank*B .. rank*B+B-1 (seeds 1234+i / 4321+i)
     Y = torch.cat([torch.from_numpy(synth.synth_spectrogram(rank * B + i, 1, F, T)) for i in range(B)]).to(dev)
@@ -211,8 +357,10 @@ def main():
 
     for _ in range(max(args.warmup, 2 if graphs_on else 0)):   # a shape's hipGraph is captured on its second pass
         x = step()
+    g0 = model.dnn.graph_launches()
     # (1) THE timed region: the product path as shipped -- each network evaluation is one hipGraph replay
     x, elapsed = timed_region()
+    graph_launches = model.dnn.graph_launches() - g0          # counted by the library, not inferred from the env
     # (2) the same K steps again with the library's per-launch HIP events (recorded on the launch stream) around the
     # dominant kernel; bracketing individual launches needs plain launches, so this region runs the identical
     # launch list eagerly.  Its wall time is reported next to the timed region's (roofline.profiled_region_*).
@@ -226,7 +374,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         per_rank_ms = [1e3 * float(v) / args.steps for v in tt.tolist()]
         elapsed = float(tt.max().item())
-    assert os.environ.get("FLOWSE_BENCH_NO_CHECK") or torch.isfinite(torch.view_as_real(x)).all(), "non-finite output"
+    checked = not os.environ.get("FLOWSE_BENCH_NO_CHECK")      # measurement hook (what-if builds); echoed into the line
+    assert not checked or torch.isfinite(torch.view_as_real(x)).all(), "non-finite output"
 
     frames_total = world * args.steps * B * T
     value = frames_total / elapsed
@@ -236,10 +385,7 @@ def main():
         "metric": f"enhanced spectrogram-frames/sec at N={NS} solver steps",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 (3x3 convs as split-bf16 x3 MFMA, fp32 accumulate)",
-                                       "bf16": "bf16 operands in the 3x3 convs, fp32 accumulate/activations",
-                                       "fp16": "fp16 operands in the 3x3 convs, fp32 accumulate/activations"}[args.precision],
-        "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPE_NAMES[args.precision], "data": "synthetic",
         "config": {"workload": f"BASELINE config[1]: batch={B} synthetic complex spectrograms [{B},1,{F},{T}] per GPU, "
                                f"N={NS} {args.solver} steps ({nfe_per_step} NFE), NCSN++ (65.6M params, synthetic "
                                f"weights), precision mode {args.precision}",
@@ -247,7 +393,8 @@ def main():
                    "parallelism": f"dp{world} (per-utterance, final RCCL gather only)",
                    "collective_backend": (backend if world > 1 else None),
                    "ranks_share_one_device": share if world > 1 else False,
-                   "hip_graph_replay": graphs_on,
+                   "hip_graph_replay": graph_launches > 0, "hip_graph_launches": graph_launches,
+                   "finite_output_checked": checked,
                    "workspace_GB": round(ws_bytes / 2 ** 30, 2)},
         "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
         "achieved_TFLOPs_whole_path": value * nfe_per_step * FLOP_PER_FRAME_NFE / world / 1e12,
@@ -367,6 +514,37 @@ def main():
                         alts[mode]["roofline"]["whole_path_issued_TFLOPs"] = tot["issued"] / (dt_m / args.steps) / 1e12
             model.dnn.set_precision("fp32")
             out["alt_precision"] = alts
+            # single-utterance latency shape (the reference's own usage: one utterance per sampler call, evaluate.py:97)
+            shapes = {}
+            for (b1, t1) in ((1, 256),):
+                Y1, Z1 = Y[:b1, :, :, :t1].contiguous(), Z[:b1, :, :, :t1].contiguous()
+
+                def step1():
+                    return get_white_box_solver("euler", model.ode, model, Y=Y1, Y_prior=Y1, T_rev=1.0, t_eps=0.03, N=NS,
+                                                z=Z1)()[0]
+                for _ in range(3):
+                    step1()
+                torch.cuda.synchronize()
+                reps = max(args.steps, 5)
+                t1s = time.perf_counter()
+                for _ in range(reps):
+                    step1()
+                torch.cuda.synchronize()
+                dt1 = (time.perf_counter() - t1s) / reps
+                model.dnn.profile_begin(1)
+                step1()
+                torch.cuda.synchronize()
+                pm = model.dnn.profile_end()
+                shapes[f"[{b1},1,{F},{t1}]"] = {"value": b1 * t1 / dt1, "unit": "frames/s", "ms_per_step": 1e3 * dt1,
+                                                 "ms_per_nfe": 1e3 * dt1 / NS,
+                                                 "launches_per_nfe": pm["_all_launches"]["launches"] / NS}
+            out["alt_shapes"] = shapes
+            # one GPU's share of BASELINE config[3] at 8 GPUs (824 / 8 = 103 ragged utterances) through enhance_sharded
+            a2 = argparse.Namespace(**vars(args))
+            a2.utts, a2.steps, a2.warmup = VBDMD_UTTS // 8, 1, 2
+            vb = run_vbdmd(a2, model, dev, 1, 0, backend, False)
+            out["alt_workloads"] = {"vbdmd_one_gpu_share": {k: vb[k] for k in ("value", "unit", "ms_per_step", "config",
+                                                                              "frames_value_counts")}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, NS, T, args.cpu_reps)
             out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]

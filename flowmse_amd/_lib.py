@@ -56,6 +56,8 @@ SIGNATURES = {
     "flowse_vf_forward": (_i, [_vp, _vp, _vp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "flowse_prior_sample": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
     "flowse_euler_sample": (_i, [_vp, _vp, _vp, C.POINTER(_f), C.POINTER(_f), _i, _i, _i, _i, _vp]),
+    "flowse_rk_sample": (_i, [_vp, _vp, _vp, C.POINTER(_f), C.POINTER(_f), _i, _i, _i, _i, _i, _vp]),
+    "flowse_model_graph_launches": (_i64, [_vp]),
     "flowse_axpy": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
     "flowse_stft_compress": (_i, [_fp, _i, _i, _f, _vp, _i, _i, _f, _f, _vp]),
     "flowse_istft_decompress": (_i, [_vp, _i, _i, _i, _f, _f, _fp, _i, _f, _vp]),

@@ -46,6 +46,13 @@ def _set_nested(root, dotted, param):
     mod.register_parameter(parts[-1], param)
 
 
+class _ShapeOnly:
+    """Stands in for a [B] time tensor in shape checks (the fused samplers build their times inside the library)."""
+
+    def __init__(self, shape):
+        self.shape = shape
+
+
 @BackboneRegistry.register("ncsnpp")
 class NCSNpp(nn.Module):
     @staticmethod
@@ -139,8 +146,20 @@ class NCSNpp(nn.Module):
 
     # ------------------------------------------------------------------ weights -> library
     def _params_in_order(self):
+        """Parameter objects in the library's table order.  The list is cached (the per-call cost of the sampler
+        plugins' VF_fn calls must stay at a version scan, not a module-tree walk) and rebuilt whenever a parameter
+        object was replaced (``_apply`` with tensor swapping, ``register_parameter``, ...)."""
+        cached = self.__dict__.get("_plist")
+        if cached is not None and all(a is b for a, b in zip(cached[1], self._parameters_identity())):
+            return cached[0]
         sd = dict(self.named_parameters())
-        return [sd[n] for n in self._param_names]
+        plist = [sd[n] for n in self._param_names]
+        self.__dict__["_plist"] = (plist, self._parameters_identity())
+        return plist
+
+    def _parameters_identity(self):
+        # two cheap witnesses that the module tree still holds the cached parameter objects
+        return (self.output_layer._parameters.get("weight"), self.all_modules[3]._parameters.get("weight"))
 
     def canonical_blob(self):
         """Flat float32 CPU tensor of all parameters in reference order / layout."""
@@ -157,10 +176,21 @@ class NCSNpp(nn.Module):
         self._uploaded_versions = [p._version for p in self._params_in_order()]
         self._uploaded_device = torch.cuda.current_device()
 
+    def mark_dirty(self):
+        """Force a weight re-upload before the next call (set by load_state_dict / .to() / precision changes; call it
+        yourself after mutating parameters through ``.data`` -- such writes do not bump ``Parameter._version``)."""
+        self._uploaded_versions = None
+
     def _ensure_uploaded(self, device):
         if self._uploaded_versions is None or self._uploaded_device != device.index or \
                 self._uploaded_versions != [p._version for p in self._params_in_order()]:
             self.upload_weights(device)
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.__dict__.pop("_plist", None)
+        self._uploaded_versions = None
+        return r
 
     # ------------------------------------------------------------------ calls
     def _check_io(self, x, y, t):
@@ -193,10 +223,14 @@ class NCSNpp(nn.Module):
             raise ValueError(f"expected complex input [B,2,F,T], got {tuple(x.shape)}")
         return self.vf_call(x[:, 0:1], time_cond, x[:, 1:2], 0)
 
-    def euler_sample(self, x, y, ts, dts):
-        """In-place N-step Euler integration on x (see flowse_euler_sample in include/flowse_hip.h)."""
-        t0 = torch.empty(x.shape[0], device=x.device)
-        self._check_io(x, y, t0)
+    TABLEAUS = {"euler": 0, "heun": 1, "rk4": 2}
+
+    def rk_sample(self, x, y, ts, dts, tableau="euler"):
+        """In-place N-step fixed-step integration on x: one C-ABI call for the whole loop (flowse_rk_sample in
+        include/flowse_hip.h; 'euler' = the reference's solver, 'heun' / 'rk4' the plugin solvers)."""
+        if x.dim() != 4:
+            raise ValueError(f"expected x of shape [B,1,F,T], got {tuple(x.shape)}")
+        self._check_io(x, y, _ShapeOnly((x.shape[0],)))
         if not (x.is_contiguous() and y.is_contiguous()):
             raise ValueError("x and y must be contiguous")
         self._ensure_uploaded(x.device)
@@ -205,9 +239,17 @@ class NCSNpp(nn.Module):
         dts_a = (C.c_float * N)(*[float(v) for v in dts])
         B, _, F, T = x.shape
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib.flowse_euler_sample(self._handle, _lib.ptr(x), _lib.ptr(y), ts_a, dts_a, N, B, F, T,
-                                                    _lib.current_stream()))
+            _lib.check(_lib.lib.flowse_rk_sample(self._handle, _lib.ptr(x), _lib.ptr(y), ts_a, dts_a, N,
+                                                 self.TABLEAUS[tableau], B, F, T, _lib.current_stream()))
         return x
+
+    def euler_sample(self, x, y, ts, dts):
+        """In-place N-step Euler integration on x (see flowse_euler_sample in include/flowse_hip.h)."""
+        return self.rk_sample(x, y, ts, dts, "euler")
+
+    def graph_launches(self):
+        """hipGraph launches this handle has made so far (0 = every evaluation ran as plain launches)."""
+        return int(_lib.lib.flowse_model_graph_launches(self._handle))
 
     def reserve(self, B, F, T):
         self._ensure_uploaded(torch.device("cuda", torch.cuda.current_device()))
@@ -236,6 +278,7 @@ class NCSNpp(nn.Module):
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
+        self.__dict__.pop("_plist", None)
         self._uploaded_versions = None
         return r
 

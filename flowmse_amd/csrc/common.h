@@ -363,6 +363,13 @@ struct CallBlock {
     float* out;
     int mode;           // see launch_head
     float dt;
+    // mode 3 (one stage of a fixed-step Runge-Kutta step, flowse_rk_sample): with v = the network output,
+    //   out     = x0     + a * v   (the next stage's input; skipped when out == null)
+    //   acc_out = acc_in + b * v   (the running combination of slopes; skipped when acc_out == null)
+    const float* x0 = nullptr;
+    const float* acc_in = nullptr;
+    float* acc_out = nullptr;
+    float a = 0.f, b = 0.f;
 };
 int launch_set_call(CallBlock* d_cb, const CallBlock& value, hipStream_t s);
 // d_ts[i * B + b] = ts[i] for i < N (ts: host values, passed to the kernel by value in chunks)
@@ -379,6 +386,7 @@ int launch_linear(const float* in, int B, int K, const float* W, const float* bi
 //   mode 0: out = v            (NCSNpp.forward)
 //   mode 1: out = -v           (VFModel.forward)
 //   mode 2: out = x + dt * v   (Euler update  x + VF * (-dt), VF = -v); out may alias x
+//   mode 3: Runge-Kutta stage (call block only): out = x0 + a * v and / or acc_out = acc_in + b * v
 int launch_head(const float* pyr4, const float* t, const float* Wout /*[2][4]*/, const float* bout /*[2]*/,
                 int B, int F, int T, int mode, const float* x_c64, float dt, float* out_c64, hipStream_t s,
                 const CallBlock* cb = nullptr);

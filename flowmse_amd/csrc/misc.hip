@@ -103,12 +103,22 @@ __global__ __launch_bounds__(256) void head_kernel(const float4* __restrict__ py
                                                    int64_t n, int64_t per_sample, int mode,
                                                    const float2* __restrict__ x, float dt, float2* __restrict__ out,
                                                    const CallBlock* __restrict__ cb) {
+    const float2* acc_in = nullptr;
+    float2* acc_out = nullptr;
+    float ca = 0.f, cbk = 0.f;
     if (cb) {
         t = cb->t;
         x = reinterpret_cast<const float2*>(cb->x);
         out = reinterpret_cast<float2*>(cb->out);
         mode = cb->mode;
         dt = cb->dt;
+        if (mode == 3) {                 // Runge-Kutta stage: x = the step's base point, not the network input
+            x = reinterpret_cast<const float2*>(cb->x0);
+            acc_in = reinterpret_cast<const float2*>(cb->acc_in);
+            acc_out = reinterpret_cast<float2*>(cb->acc_out);
+            ca = cb->a;
+            cbk = cb->b;
+        }
     }
     const float w00 = Wout[0], w01 = Wout[1], w02 = Wout[2], w03 = Wout[3];
     const float w10 = Wout[4], w11 = Wout[5], w12 = Wout[6], w13 = Wout[7];
@@ -126,6 +136,16 @@ __global__ __launch_bounds__(256) void head_kernel(const float4* __restrict__ py
             const float2 xv = x[i];
             re = xv.x + __fmul_rn(re, dt);
             im = xv.y + __fmul_rn(im, dt);
+        } else if (mode == 3) {
+            if (acc_out) {
+                const float2 av = acc_in[i];
+                acc_out[i] = make_float2(av.x + __fmul_rn(re, cbk), av.y + __fmul_rn(im, cbk));
+            }
+            if (out) {
+                const float2 xv = x[i];
+                out[i] = make_float2(xv.x + __fmul_rn(re, ca), xv.y + __fmul_rn(im, ca));
+            }
+            continue;
         }
         out[i] = make_float2(re, im);
     }

@@ -175,6 +175,13 @@ struct flowse_model {
     unsigned* d_ticket = nullptr;          // split-K arrival counters, one per output tile (zero between launches)
     int device = -1;                       // HIP device that owns every d_* buffer of this handle
     bool use_graph = true;                 // FLOWSE_NO_GRAPH=1: always launch eagerly
+    // Callers on the NULL (legacy default) stream -- PyTorch's default stream IS the NULL stream -- cannot be captured;
+    // their work runs on this internal stream instead, fenced against the NULL stream by events on both sides.
+    hipStream_t gstream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    int64_t graph_launches = 0;            // hipGraphLaunch calls made by this handle (flowse_model_graph_launches)
+    float* d_rk = nullptr;                 // fixed-step RK scratch: stage input + slope accumulator, 2 x [B,1,F,T] complex64
+    size_t d_rk_floats = 0;
     // single-module handles (flowse_block_create): one ResnetBlockBigGANpp / AttnBlockpp / Combine behind the same
     // weight packer, plan builder and kernels as the full network -- unit parity against the reference's modules
     int block_kind = -1;                   // -1: full network; else FLOWSE_BLOCK_*
@@ -1105,16 +1112,21 @@ static int run_plan(flowse_model* m, Plan* p, hipStream_t s) {
 // setup); second call: the same launch list is captured into a hipGraph; afterwards one hipGraphLaunch per call.
 // Profiling (per-launch events), the NULL stream and FLOWSE_NO_GRAPH=1 keep the eager path.
 static int exec_plan(flowse_model* m, Plan* p, hipStream_t s) {
-    if (!m->use_graph || m->prof_mode != -1 || s == nullptr) return run_plan(m, p, s);
+    if (!m->use_graph || m->prof_mode != -1 || s == nullptr) return run_plan(m, p, s);   // (NULL: see enter_stream)
     if (p->exec) {
         FLOWSE_HIP(hipGraphLaunch(p->exec, s));
+        ++m->graph_launches;
         return OK;
     }
     if (p->eager_runs < 1) {
         ++p->eager_runs;
         return run_plan(m, p, s);
     }
-    FLOWSE_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();                    // e.g. the caller's stream is already capturing: stay eager
+        m->use_graph = false;
+        return run_plan(m, p, s);
+    }
     const int rc = run_plan(m, p, s);
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(s, &g);
@@ -1138,6 +1150,30 @@ static int exec_plan(flowse_model* m, Plan* p, hipStream_t s) {
     p->graph = g;
     p->exec = ex;
     FLOWSE_HIP(hipGraphLaunch(p->exec, s));
+    ++m->graph_launches;
+    return OK;
+}
+
+// Stream the work of one C-ABI call runs on.  A real stream: that stream.  The NULL stream: it cannot be captured, so
+// (unless graphs are off / a profile is being taken) the call moves to the handle's internal stream, which first waits
+// for everything the caller has enqueued on the NULL stream; leave_stream() makes the NULL stream wait for the call.
+static int enter_stream(flowse_model* m, hipStream_t caller, hipStream_t* work) {
+    *work = caller;
+    if (caller != nullptr || !m->use_graph || m->prof_mode != -1) return OK;
+    if (!m->gstream) {
+        FLOWSE_HIP(hipStreamCreateWithFlags(&m->gstream, hipStreamNonBlocking));
+        FLOWSE_HIP(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
+        FLOWSE_HIP(hipEventCreateWithFlags(&m->ev_out, hipEventDisableTiming));
+    }
+    FLOWSE_HIP(hipEventRecord(m->ev_in, nullptr));
+    FLOWSE_HIP(hipStreamWaitEvent(m->gstream, m->ev_in, 0));
+    *work = m->gstream;
+    return OK;
+}
+static int leave_stream(flowse_model* m, hipStream_t caller, hipStream_t work) {
+    if (work == caller) return OK;
+    FLOWSE_HIP(hipEventRecord(m->ev_out, work));
+    FLOWSE_HIP(hipStreamWaitEvent(caller, m->ev_out, 0));
     return OK;
 }
 
@@ -1212,6 +1248,14 @@ static void free_device_state(flowse_model* m) {
     if (m->d_call) (void)hipFree(m->d_call);
     if (m->d_ticket) (void)hipFree(m->d_ticket);
     m->d_ticket = nullptr;
+    if (m->d_rk) (void)hipFree(m->d_rk);
+    m->d_rk = nullptr;
+    m->d_rk_floats = 0;
+    if (m->gstream) (void)hipStreamDestroy(m->gstream);
+    if (m->ev_in) (void)hipEventDestroy(m->ev_in);
+    if (m->ev_out) (void)hipEventDestroy(m->ev_out);
+    m->gstream = nullptr;
+    m->ev_in = m->ev_out = nullptr;
     for (hipEvent_t e : m->prof_pool) (void)hipEventDestroy(e);
     m->prof_pool.clear();
     m->prof_used = 0;
@@ -1348,15 +1392,21 @@ int flowse_model_set_precision(flowse_model* m, int mode) {
         return ERR_ARG;
     }
     if (mode != m->precision) {
-        m->precision = mode;
-        if (m->d_w) {            // weights must be re-uploaded so that the bf16 planes match the mode
-            if (const int rc = check_device(m)) return rc;
+        if (m->d_w) {            // weights must be re-uploaded so that the operand planes match the mode
+            if (const int rc = check_device(m)) return rc;      // before any state changes: a failure leaves the handle as is
             FLOWSE_HIP(hipDeviceSynchronize());
             clear_plans(m);
             FLOWSE_HIP(hipFree(m->d_w));
             m->d_w = nullptr;
             m->d_w_numel = 0;
+            if (m->d_w16) {      // the 16-bit twin belongs to the mode that is being left
+                FLOWSE_HIP(hipFree(m->d_w16));
+                m->d_w16 = nullptr;
+                m->d_w16_numel = 0;
+            }
         }
+        m->precision = mode;
+        m->act_dt = DT_F32;      // recomputed by the next flowse_model_load_weights
         clear_plans(m);
     }
     return OK;
@@ -1485,11 +1535,14 @@ int flowse_vf_forward(flowse_model* m, const void* x, const void* y, const float
     Plan* p = nullptr;
     int rc = get_plan(m, B, F, T, &p);
     if (rc != OK) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t caller = static_cast<hipStream_t>(stream), s = nullptr;
+    rc = enter_stream(m, caller, &s);
+    if (rc != OK) return rc;
     CallBlock cb{static_cast<const float*>(x), static_cast<const float*>(y), t, static_cast<float*>(out), mode, 0.f};
     rc = launch_set_call(m->d_call, cb, s);
-    if (rc != OK) return rc;
-    return exec_plan(m, p, s);
+    if (rc == OK) rc = exec_plan(m, p, s);
+    const int rc2 = leave_stream(m, caller, s);
+    return rc != OK ? rc : rc2;
 }
 
 int flowse_prior_sample(const void* y, const void* z, float sigma, void* x_out, int64_t numel_complex, void* stream) {
@@ -1505,37 +1558,109 @@ int flowse_axpy(const void* x, const void* k, float dt, void* out, int64_t numel
     return flowse_prior_sample(x, k, dt, out, numel_complex, stream);
 }
 
-int flowse_euler_sample(flowse_model* m, void* x_inout, const void* y, const float* ts, const float* dts, int N, int B,
-                        int F, int T, void* stream) {
-    if (!m || !x_inout || !y || !ts || !dts || N < 1) {
-        set_error("flowse_euler_sample: bad argument");
-        return ERR_ARG;
-    }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    Plan* p = nullptr;
-    int rc = get_plan(m, B, F, T, &p);
-    if (rc != OK) return rc;
-    const size_t need = (size_t)N * B;
+static int reserve_times(flowse_model* m, size_t need) {
     if (need > m->d_ts_floats) {
         FLOWSE_HIP(hipDeviceSynchronize());
         if (m->d_ts) FLOWSE_HIP(hipFree(m->d_ts));
         m->d_ts = nullptr;
+        m->d_ts_floats = 0;
         FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_ts), need * sizeof(float)));
         m->d_ts_floats = need;
     }
-    // vec_t = ones(B) * t (sampling/__init__.py:55), written on the device by a kernel that receives the times by value
-    rc = launch_fill_times(m->d_ts, ts, N, B, s);
-    if (rc != OK) return rc;
-    for (int i = 0; i < N; ++i) {
-        CallBlock cb{static_cast<const float*>(x_inout), static_cast<const float*>(y), m->d_ts + (size_t)i * B,
-                     static_cast<float*>(x_inout), 2, dts[i]};
-        rc = launch_set_call(m->d_call, cb, s);
-        if (rc != OK) return rc;
-        rc = exec_plan(m, p, s);
-        if (rc != OK) return rc;
-    }
     return OK;
 }
+
+int flowse_euler_sample(flowse_model* m, void* x_inout, const void* y, const float* ts, const float* dts, int N, int B,
+                        int F, int T, void* stream) {
+    return flowse_rk_sample(m, x_inout, y, ts, dts, N, FLOWSE_TABLEAU_EULER, B, F, T, stream);
+}
+
+// Fixed-step explicit Runge-Kutta over the reference's grid (see include/flowse_hip.h).  With v = dnn(cat[x, y], t)
+// (so VF = -v) and h = dts[i] > 0 a step from t to t - h is
+//   euler:  x += h v(x, t)
+//   heun:   v1 = v(x, t), v2 = v(x + h v1, t - h);                    x += h/2 (v1 + v2)
+//   rk4:    v1 = v(x, t), v2 = v(x + h/2 v1, t - h/2), v3 = v(x + h/2 v2, t - h/2), v4 = v(x + h v3, t - h);
+//           x += h/6 (v1 + 2 v2 + 2 v3 + v4)
+// Every stage is one network evaluation whose head kernel (mode 3) writes the next stage's input and folds the slope
+// into the accumulator; no separate axpy launches, no host synchronisation.
+int flowse_rk_sample(flowse_model* m, void* x_inout, const void* y, const float* ts, const float* dts, int N, int tableau,
+                     int B, int F, int T, void* stream) {
+    if (!m || !x_inout || !y || !ts || !dts || N < 1 || tableau < FLOWSE_TABLEAU_EULER || tableau > FLOWSE_TABLEAU_RK4) {
+        set_error("flowse_rk_sample / flowse_euler_sample: bad argument");
+        return ERR_ARG;
+    }
+    Plan* p = nullptr;
+    int rc = get_plan(m, B, F, T, &p);
+    if (rc != OK) return rc;
+    const int stages = tableau == FLOWSE_TABLEAU_RK4 ? 4 : tableau == FLOWSE_TABLEAU_HEUN ? 2 : 1;
+    // a step that ends at (or numerically below) t = 0 is the reference's own Euler update: the field divides by t and
+    // embeds log t, so no stage may be evaluated at the end point of such a step (it is the LAST step of the reference's
+    // grid, whose length equals the last grid time, sampling/__init__.py:53)
+    std::vector<float> nfe_t;
+    std::vector<int> step_stages(N);
+    for (int i = 0; i < N; ++i) {
+        const float t = ts[i], h = dts[i];
+        const bool lands = (double)t - (double)h <= 1e-6 * std::max(1.0, std::fabs((double)t));
+        const int st = lands ? 1 : stages;
+        step_stages[i] = st;
+        const float dt = -h;
+        nfe_t.push_back(t);
+        if (st == 2) nfe_t.push_back(t + dt);
+        if (st == 4) {
+            const float th = t + 0.5f * dt;
+            nfe_t.push_back(th);
+            nfe_t.push_back(th);
+            nfe_t.push_back(t + dt);
+        }
+    }
+    rc = reserve_times(m, nfe_t.size() * (size_t)B);
+    if (rc != OK) return rc;
+    const size_t state = (size_t)2 * B * F * T;                 // floats of one complex64 [B,1,F,T] tensor
+    if (stages > 1 && m->d_rk_floats < 2 * state) {
+        FLOWSE_HIP(hipDeviceSynchronize());
+        if (m->d_rk) FLOWSE_HIP(hipFree(m->d_rk));
+        m->d_rk = nullptr;
+        m->d_rk_floats = 0;
+        FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_rk), 2 * state * sizeof(float)));
+        m->d_rk_floats = 2 * state;
+    }
+    hipStream_t caller = static_cast<hipStream_t>(stream), s = nullptr;
+    rc = enter_stream(m, caller, &s);
+    if (rc != OK) return rc;
+    // vec_t = ones(B) * t (sampling/__init__.py:55), written on the device by a kernel that receives the times by value
+    rc = launch_fill_times(m->d_ts, nfe_t.data(), (int)nfe_t.size(), B, s);
+    float* const x = static_cast<float*>(x_inout);
+    const float* const yy = static_cast<const float*>(y);
+    float* const xs = m->d_rk;                                   // stage input
+    float* const acc = m->d_rk ? m->d_rk + state : nullptr;      // x + sum_j b_j h v_j so far
+    size_t k = 0;                                                // index of the next network evaluation
+    auto stage = [&](const float* in, float* out, const float* acc_in, float* acc_out, float a, float b) {
+        CallBlock cb{in, yy, m->d_ts + (k++) * B, out, 3, 0.f, x, acc_in, acc_out, a, b};
+        int r = launch_set_call(m->d_call, cb, s);
+        if (r == OK) r = exec_plan(m, p, s);
+        return r;
+    };
+    for (int i = 0; i < N && rc == OK; ++i) {
+        const float h = dts[i];
+        if (step_stages[i] == 1) {
+            CallBlock cb{x, yy, m->d_ts + (k++) * B, x, 2, h};
+            rc = launch_set_call(m->d_call, cb, s);
+            if (rc == OK) rc = exec_plan(m, p, s);
+        } else if (step_stages[i] == 2) {
+            rc = stage(x, xs, x, acc, h, 0.5f * h);
+            if (rc == OK) rc = stage(xs, nullptr, acc, x, 0.f, 0.5f * h);
+        } else {
+            rc = stage(x, xs, x, acc, 0.5f * h, h / 6.0f);
+            if (rc == OK) rc = stage(xs, xs, acc, acc, 0.5f * h, h / 3.0f);
+            if (rc == OK) rc = stage(xs, xs, acc, acc, h, h / 3.0f);
+            if (rc == OK) rc = stage(xs, nullptr, acc, x, 0.f, h / 6.0f);
+        }
+    }
+    const int rc2 = leave_stream(m, caller, s);
+    return rc != OK ? rc : rc2;
+}
+
+int64_t flowse_model_graph_launches(const flowse_model* m) { return m ? m->graph_launches : 0; }
 
 int flowse_stft_compress(const float* sig, int B, int L, float scale_in, void* out_c64, int T, int Tpad, float factor,
                          float exponent, void* stream) {

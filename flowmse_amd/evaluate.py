@@ -50,7 +50,7 @@ def enhance_waveform(model, y, N=5, T_rev=1.0, t_eps=0.03, odesolver="euler", z=
     dm = model.data_module
     fused = VF_fn is None and hasattr(dm, "fused_ok") and dm.fused_ok(y.to(device))
     if fused:                      # STFT + compression + frame padding as one HIP kernel
-        Y = dm.analyze(y.to(device), 1.0 / norm_factor)
+        Y = dm.analyze(y.to(device) / norm_factor)       # y / max|y| as the reference computes it (evaluate.py:111)
     else:
         y = y / norm_factor
         Y = torch.unsqueeze(model._forward_transform(model._stft(y.to(device))), 0)
@@ -72,7 +72,7 @@ def enhance_batch(model, ys, N=5, T_rev=1.0, t_eps=0.03, odesolver="euler"):
     dm = model.data_module
     fused = hasattr(dm, "fused_ok") and all(dm.fused_ok(y) for y in ys)
     if fused:                      # STFT + compression + frame padding: one HIP kernel per utterance
-        specs = [dm.analyze(y, 1.0 / n) for y, n in zip(ys, norms)]
+        specs = [dm.analyze(y / n) for y, n in zip(ys, norms)]
     else:
         specs = [pad_spec(torch.unsqueeze(model._forward_transform(model._stft(y / n)), 0)) for y, n in zip(ys, norms)]
     Y = torch.cat(specs, dim=0)
@@ -87,7 +87,10 @@ def enhance_batch(model, ys, N=5, T_rev=1.0, t_eps=0.03, odesolver="euler"):
 def _write_wav(path, x, sr=16000):
     """16-bit PCM WAV like the reference's ``soundfile.write(path, x_hat, 16000)`` (evaluate.py:147; libsndfile's
     default subtype for .wav is PCM_16, float samples scaled by 0x7FFF and rounded to nearest).  soundfile itself is
-    used when importable, so output trees diff cleanly against the reference's."""
+    used when importable, so output trees diff cleanly against the reference's.  Without it scipy writes the same
+    samples: libsndfile does NOT clip by default (SFC_SET_CLIPPING off), a sample with |x| > 1 -- possible after the
+    rescale by max|y| -- keeps the low 16 bits of its rounded value, and the fallback reproduces exactly that
+    wrap-around instead of saturating, so the two writers agree bit for bit on every input."""
     x = np.asarray(x, dtype=np.float32)
     try:
         import soundfile
@@ -96,7 +99,7 @@ def _write_wav(path, x, sr=16000):
     except ImportError:
         pass
     from scipy.io import wavfile
-    pcm = np.clip(np.rint(x.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+    pcm = np.rint(x.astype(np.float64) * 32767.0).astype(np.int64).astype(np.uint16).astype(np.int16)
     wavfile.write(path, sr, pcm)
 
 

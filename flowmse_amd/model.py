@@ -179,6 +179,10 @@ class VFModel(nn.Module):
         """Fused N-step Euler loop, in place on x (used by sampling.get_white_box_solver)."""
         return self.dnn.euler_sample(x, y, timesteps, stepsizes)
 
+    def rk_sample_(self, x, y, timesteps, stepsizes, tableau):
+        """Fused N-step fixed-step loop ('euler' | 'heun' | 'rk4'), in place on x: one library call, no host sync."""
+        return self.dnn.rk_sample(x, y, timesteps, stepsizes, tableau)
+
     # ------------------------------------------------------------------ spectrogram helpers (model.py:190-203)
     def to_audio(self, spec, length=None):
         return self._istft(self._backward_transform(spec), length)

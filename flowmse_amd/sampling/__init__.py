@@ -4,10 +4,12 @@
 t_eps, N)`` time grid, step sizes ``t_i - t_{i+1}`` with the LAST step equal to ``t_{N-1}`` (so the trajectory
 ends at t = 0), N solver updates, returns ``(x, N)``.
 
-When ``VF_fn`` is a HIP-backed :class:`flowmse_amd.model.VFModel` and the solver is ``'euler'`` the whole loop
-runs as one C-ABI call (``flowse_euler_sample``): N x (NCSN++ forward + fused Euler update) enqueued on the
-current stream with no host synchronisation.  Any other callable ``VF_fn`` / registered solver goes through
-the generic plugin loop, exactly like the reference.
+When ``VF_fn`` is a HIP-backed :class:`flowmse_amd.model.VFModel` and the solver is one the library implements
+(``'euler'``, the reference's; ``'heun'`` / ``'rk4'``, the fixed-step plugins) the whole loop runs as one C-ABI call
+(``flowse_rk_sample``): N x stages x (NCSN++ forward + solver update fused into the head kernel) enqueued on the
+current stream with no host synchronisation.  Any other callable ``VF_fn`` / registered solver goes through the
+generic plugin loop, exactly like the reference; that loop keeps its time grid on the host, so it never reads a
+device tensor back either.
 """
 import torch
 
@@ -30,7 +32,8 @@ def get_white_box_solver(odesolver_name, ode, VF_fn, Y, Y_prior=None, T_rev=1.0,
     """Returns ``ode_solver() -> (x_result, N)``.  Extra keyword ``z``: explicit prior noise (reproducibility)."""
     odesolver_cls = ODEsolverRegistry.get_by_name(odesolver_name)
     odesolver = odesolver_cls(ode, VF_fn)
-    fused = (odesolver_name == "euler" and hasattr(VF_fn, "euler_sample_") and Y.is_cuda)
+    fused = (getattr(odesolver_cls, "fused_tableau", None) is not None and hasattr(VF_fn, "rk_sample_")
+             and Y.is_cuda)
 
     def ode_solver(Y_prior=Y_prior):
         with torch.no_grad():
@@ -44,14 +47,20 @@ def get_white_box_solver(odesolver_name, ode, VF_fn, Y, Y_prior=None, T_rev=1.0,
             # host copy of the grid: the values equal torch.linspace(..., device=Y.device) of the reference
             timesteps, stepsizes = time_grid(T_rev, t_eps, N)
             if fused:
-                xt = VF_fn.euler_sample_(xt.contiguous(), Y.contiguous(), timesteps.tolist(), stepsizes.tolist())
+                xt = VF_fn.rk_sample_(xt.contiguous(), Y.contiguous(), timesteps.tolist(), stepsizes.tolist(),
+                                      odesolver_cls.fused_tableau)
                 return xt, N
-            timesteps = timesteps.to(Y.device)
-            for i in range(N):
-                t = timesteps[i]
-                stepsize = stepsizes[i].to(Y.device)
-                vec_t = torch.ones(Y.shape[0], device=Y.device) * t
-                xt = odesolver.update_fn(xt, vec_t, Y, stepsize)
+            try:
+                for i in range(N):
+                    # t and the step size stay host values (0-d CPU tensors): `ones(B) * t` is a fill kernel with a
+                    # scalar argument, and a solver may inspect the step ("does it land on t = 0?") with no readback
+                    t = timesteps[i]
+                    stepsize = stepsizes[i]
+                    vec_t = torch.ones(Y.shape[0], device=Y.device) * float(t)
+                    odesolver.step_start_time = float(t)
+                    xt = odesolver.update_fn(xt, vec_t, Y, stepsize)
+            finally:
+                odesolver.step_start_time = None
             return xt, N
 
     return ode_solver

@@ -9,6 +9,10 @@
  *     weights and workspace are owned by the model handle.  Exception: arguments documented "host".
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue work and return;
  *     they never synchronise the device (flowse_model_load_weights and flowse_model_reserve may allocate).
+ *     The NULL (legacy default) stream cannot be captured into a hipGraph, so for stream == NULL the model handle runs
+ *     the call on an internal stream fenced by events against the NULL stream on both sides: the call is ordered after
+ *     everything enqueued on the NULL stream before it, and later NULL-stream work is ordered after the call -- the same
+ *     ordering a launch on the NULL stream itself would have had (PyTorch's default stream is the NULL stream).
  *   - One handle per GPU per process; calls on one handle must be serialised by the caller (the reference is
  *     single-threaded, single-stream, torch.no_grad()).
  *   - Boundary tensors follow the reference: complex64 interleaved (re, im), [B, 1, F, T] contiguous
@@ -36,7 +40,7 @@ extern "C" {
 #define FLOWSE_ERR_STATE 3
 #define FLOWSE_ERR_SHAPE 4
 
-#define FLOWSE_ABI_VERSION 1
+#define FLOWSE_ABI_VERSION 2
 #define FLOWSE_MAX_LEVELS 8
 #define FLOWSE_MAX_ATTN 4
 
@@ -136,10 +140,26 @@ int flowse_prior_sample(const void* y, const void* z, float sigma, void* x_out, 
  * ts, dts: HOST float32 arrays of length N (the caller reproduces torch.linspace and the step rule, including
  * the final step dts[N-1] = ts[N-1]); they are consumed before the call returns (passed to the device as kernel
  * arguments, no asynchronous host copy).  No host synchronisation.  Each network evaluation is one hipGraph launch
- * (the launch list of a shape is captured on its second use; FLOWSE_NO_GRAPH=1, the NULL stream and an active
- * flowse_profile_begin keep plain launches). */
+ * (the launch list of a shape is captured on its second use; FLOWSE_NO_GRAPH=1 and an active flowse_profile_begin keep
+ * plain launches; flowse_model_graph_launches() counts the graph launches a handle has made). */
 int flowse_euler_sample(flowse_model* m, void* x_inout, const void* y, const float* ts, const float* dts, int N,
                         int B, int F, int T, void* stream);
+/* The same loop with a fixed-step explicit Runge-Kutta update per grid step (BASELINE config 5's "N = 25 RK solver").
+ * The reference has no fixed-step RK -- its only Runge-Kutta is scipy's adaptive RK45 black box
+ * (flowmse/sampling/__init__.py:64-114) -- so this is the reference's white-box loop (sampling/__init__.py:45-57, same
+ * grid and step rule) with the update of an ODEsolverRegistry plugin (sampling/odesolvers.py:9-34) in place of
+ * EulerODEsolver.update_fn.  tableau: FLOWSE_TABLEAU_EULER (== flowse_euler_sample), _HEUN (explicit trapezoid, 2
+ * network evaluations per step) or _RK4 (classical, 4 per step).  A step that ends at t = 0 -- the last step of the
+ * reference's grid -- is taken as the reference's Euler update: the field divides by t (ncsnpp.py:398) and embeds
+ * log t, so no stage is ever evaluated at t <= 0.  Stages are chained through the head kernel (next stage input and
+ * slope accumulation fused into it): no extra launches, no host synchronisation, each evaluation one hipGraph launch. */
+#define FLOWSE_TABLEAU_EULER 0
+#define FLOWSE_TABLEAU_HEUN 1
+#define FLOWSE_TABLEAU_RK4 2
+int flowse_rk_sample(flowse_model* m, void* x_inout, const void* y, const float* ts, const float* dts, int N,
+                     int tableau, int B, int F, int T, void* stream);
+/* Number of hipGraphLaunch calls this handle has issued so far (0 while every evaluation ran as plain launches). */
+int64_t flowse_model_graph_launches(const flowse_model* m);
 /* One generic explicit update from a caller-held slope: x <- x + dt * k (complex64 as float pairs). */
 int flowse_axpy(const void* x, const void* k, float dt, void* out, int64_t numel_complex, void* stream);
 

@@ -89,10 +89,19 @@ def test_fixed_step_rk_against_oracle_composition(tiny, solver, N):
     cfg = O.make_cfg(**C.TINY)
     _, y, z = C.tiny_inputs()
     want = S.rk_sample(lambda x, tt, yy: O.vf_forward(w, cfg, x, tt, yy), y, z, tableau=solver, N=N)
-    got, n = get_white_box_solver(solver, tiny.ode, tiny, Y=y.cuda(), N=N, z=z.cuda())()
+    g0 = tiny.dnn.graph_launches()
+    got, n = get_white_box_solver(solver, tiny.ode, tiny, Y=y.cuda(), N=N, z=z.cuda())()     # fused: flowse_rk_sample
+    got = got.clone()
+    nfe = (N - 1) * {"heun": 2, "rk4": 4}[solver] + 1
+    assert tiny.dnn.graph_launches() - g0 in (nfe, nfe - 1), "the fused RK entry did not run (one graph launch per NFE)"
     err = C.rel_l2(got.cpu(), want)
-    print(solver, "N", N, "rel-L2 vs oracle composition", err)
+    print(solver, "N", N, "fused rel-L2 vs oracle composition", err)
     assert n == N and err < 5 * TIGHT
+    # the Python plugin loop (any callable VF_fn: update_fn + flowse_axpy launches) integrates the same tableau
+    loop, n2 = get_white_box_solver(solver, tiny.ode, lambda xx, tt, yy: tiny(xx, tt, yy), Y=y.cuda(), N=N, z=z.cuda())()
+    err2 = C.rel_l2(loop.cpu(), want)
+    print(solver, "N", N, "plugin-loop rel-L2 vs oracle composition", err2, " fused vs loop", C.rel_l2(got.cpu(), loop.cpu()))
+    assert n2 == N and err2 < 5 * TIGHT and C.rel_l2(got.cpu(), loop.cpu()) < 1e-5
 
 
 def test_wide_forward_golden():
@@ -156,6 +165,79 @@ def test_full_sampler_vs_oracle_T256(full):
     assert err < TOL
 
 
+@pytest.mark.timeout(1500)
+def test_full_sampler_vs_oracle_B8_T256_N5(full):
+    """THE headline configuration at its real size -- BASELINE config[1]: [8,1,256,256], N = 5 Euler, fp32, the
+    bench's own inputs (utterances 0..7) -- against the CPU oracle (8 x 5 network evaluations, ~1-2 minutes of host time)."""
+    from flowmse_amd.sampling import get_white_box_solver
+    from oracle import ncsnpp_oracle as O
+    from oracle import sampler_oracle as S
+    tb = C.param_tables()["full"]
+    w = C.synth_weights(tb["names"], tb["shapes"])
+    B, T, N = 8, 256, 5
+    Y = torch.cat([C.c64(synth.synth_spectrogram(i, 1, 256, T)) for i in range(B)])
+    Z = torch.cat([C.c64(synth.synth_noise(i, 1, 256, T)) for i in range(B)])
+    got, n = get_white_box_solver("euler", full.ode, full, Y=Y.cuda(), Y_prior=Y.cuda(), T_rev=1.0, t_eps=0.03, N=N,
+                                  z=Z.cuda())()
+    got = got.cpu()
+    cfg = O.make_cfg()
+    worst = 0.0
+    for b in range(B):                       # the oracle is per-sample exact (no cross-sample term): one utterance at a time
+        ref, _ = S.euler_sample_net(w, cfg, Y[b:b + 1], Z[b:b + 1], N=N)
+        e = C.rel_l2(got[b:b + 1], ref)
+        worst = max(worst, e)
+        print(f"headline config sample {b}: rel-L2 vs oracle {e:.3e}")
+    assert n == N and worst < TIGHT
+
+
+@pytest.mark.timeout(1500)
+def test_full_net_ragged_set_through_enhance_sharded(full):
+    """BASELINE config[3] on one rank with the released architecture: 18 ragged utterances (true lengths 40..300 frames,
+    padded to 64 k) through enhance_sharded (LPT shard -> equal-length batches of <= 4 -> N = 3 Euler sampler -> gather)
+    must equal enhancing each utterance alone (the reference's loop, evaluate.py:97-132), and two of them are checked
+    against the CPU oracle."""
+    from flowmse_amd.parallel import enhance_sharded
+    from flowmse_amd.sampling import get_white_box_solver
+    from flowmse_amd.util.other import pad_spec
+    from oracle import ncsnpp_oracle as O
+    from oracle import sampler_oracle as S
+    lens = [64, 40, 128, 100, 192, 12, 256, 130, 70, 300, 64, 255, 129, 191, 65, 128, 200, 90]
+    N = 3
+    specs = [C.c64(synth.synth_spectrogram(500 + i, 1, 256, t))[0, 0].cuda() for i, t in enumerate(lens)]
+
+    def noise(i, T):
+        return C.c64(synth.synth_noise(700 + i, 1, 256, T))
+
+    seen = []
+
+    def sample_fn(Y, ids):
+        seen.append((Y.shape[0], Y.shape[-1]))
+        z = torch.cat([noise(i, Y.shape[-1]) for i in ids]).cuda()
+        return get_white_box_solver("euler", full.ode, full, Y=Y, N=N, z=z)()[0]
+
+    st = {}
+    out = enhance_sharded(sample_fn, specs, max_batch=4, stats=st)
+    assert len(out) == len(lens) and st["utterances"] == len(lens) and st["frames"] == sum(-(-t // 64) * 64 for t in lens)
+    assert len({T for _, T in seen}) == 5 and max(b for b, _ in seen) == 4       # 64, 128, 192, 256, 320-frame batches
+    worst = 0.0
+    for i, s in enumerate(specs):
+        Y = pad_spec(s[None, None])
+        ref = get_white_box_solver("euler", full.ode, full, Y=Y, N=N, z=noise(i, Y.shape[-1]).cuda())()[0][0, 0]
+        assert out[i].shape == s.shape
+        # batch rows vs alone: same arithmetic up to the kernels' batch-dependent K-split plans (rounding level)
+        worst = max(worst, C.rel_l2(out[i], ref[:, :lens[i]].cpu()))
+    print("ragged set: batched vs per-utterance worst rel-L2", worst)
+    assert worst < 2e-5
+    tb = C.param_tables()["full"]
+    w = C.synth_weights(tb["names"], tb["shapes"])
+    for i in (1, 3):                                            # 40 -> 64 and 100 -> 128 frames
+        Yc = pad_spec(specs[i][None, None]).cpu()
+        ref, _ = S.euler_sample_net(w, O.make_cfg(), Yc, noise(i, Yc.shape[-1]), N=N)
+        err = C.rel_l2(out[i], ref[0, 0, :, :lens[i]])
+        print(f"ragged set utterance {i} (T={lens[i]}): rel-L2 vs oracle {err:.3e}")
+        assert err < TIGHT
+
+
 @pytest.mark.parametrize("B,T", [(1, 64), (1, 192), (3, 128), (8, 64)])
 def test_full_forward_shapes_vs_oracle(full, B, T):
     """Smallest legal utterance, a frame count that is not a power of two (W = 192, 96, 48, 24, 12, 6, 3), an odd
@@ -205,11 +287,12 @@ def test_black_box_solver_matches_oracle_vf(tiny):
     assert C.rel_l2(got.cpu(), ref) < 2e-3
 
 
-@pytest.mark.parametrize("mode,bound", [("fp32", 1e-4), ("bf16x3", 1e-4), ("bf16", 5e-2), ("fp16", 5e-3)])
+@pytest.mark.parametrize("mode,bound", [("fp32", 1e-4), ("bf16x3", 1e-4), ("bf16", 2e-2), ("fp16", 2.6e-3)])
 def test_precision_modes_vs_oracle(full, mode, bound):
     """Matrix-core operand modes of the large 3x3 convs at a shape that takes the LDS-halo kernels ([2,.,256,128]:
     512 pixel tiles), against the CPU oracle.  'bf16x3' (hi/lo split, 3 bf16 MFMAs per fp32 product) must stay
-    fp32-class, far inside the 1e-3 bar; 'bf16' (BASELINE config 3) is bounded loosely and reported."""
+    fp32-class, far inside the 1e-3 bar; 'bf16' / 'fp16' (BASELINE configs 3 / 5) are held to 2x what MI355X runs
+    measure (1.0e-2 / 1.3e-3): a ceiling that an accuracy regression of the 16-bit kernels breaks."""
     from oracle import ncsnpp_oracle as O
     tb = C.param_tables()["full"]
     w = C.synth_weights(tb["names"], tb["shapes"])
@@ -228,11 +311,12 @@ def test_precision_modes_vs_oracle(full, mode, bound):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode,bound", [("bf16", 6e-2), ("fp16", 8e-3)])
+@pytest.mark.parametrize("mode,bound", [("bf16", 1e-2), ("fp16", 1.2e-3)])
 def test_16bit_sampler_vs_oracle(full, mode, bound):
     """BASELINE config 3 (bf16) / config 5 (fp16) arithmetic end to end: N = 5 Euler sampler at [2,1,256,128] with
     activations stored in 16 bits, against the fp32 CPU oracle.  The 1e-3 bar of north_star is stated for fp32; 16-bit
-    storage over ~110 layers cannot meet it ('hard parts') -- the measured error is printed and bounded."""
+    storage over ~110 layers cannot meet it ('hard parts') -- the measured error is printed and bounded at
+    about 2x the measured value (bf16 ~5e-3, half ~6e-4), so a 10x accuracy regression cannot pass."""
     from flowmse_amd.sampling import get_white_box_solver
     from oracle import ncsnpp_oracle as O
     from oracle import sampler_oracle as S
@@ -354,6 +438,45 @@ def test_graph_replay_equals_eager_launches(tiny):
     g = C.gold("tiny_sampler")
     got = get_white_box_solver("euler", tiny.ode, tiny, Y=Y, N=5, z=Z)()[0]
     assert C.rel_l2(got.cpu(), g["x_N5"]) < TIGHT
+
+
+def test_graphs_really_replay_on_the_default_and_on_side_streams():
+    """PyTorch's default stream is the NULL stream, which cannot be captured: the library then runs the call on its own
+    stream fenced against the NULL stream.  The handle's graph-launch counter proves that replays happen (round 2's test
+    compared eager launches with eager launches), on the default stream and on a caller-owned side stream, and results
+    of eager pass / capture pass / replays are bit-identical and correctly ordered against surrounding torch work."""
+    from flowmse_amd.sampling import get_white_box_solver
+    m = _model(C.TINY)                          # fresh handle: counter starts at 0
+    xt, y, z = C.tiny_inputs()
+    X, Y, Z = xt.cuda(), y.cuda(), z.cuda()
+    t = torch.tensor([0.03, 1.0], device="cuda")
+    assert torch.cuda.current_stream().cuda_stream == 0 and m.dnn.graph_launches() == 0
+    eager = m(X, t, Y).clone()                  # first use of the shape: plain launches
+    assert m.dnn.graph_launches() == 0
+    cap = m(X, t, Y).clone()                    # second use: captured, instantiated and launched as a graph
+    n1 = m.dnn.graph_launches()
+    assert n1 == 1, "the default-stream call did not go through a hipGraph"
+    rep = m(X, t, Y).clone()
+    assert m.dnn.graph_launches() == 2 and torch.equal(eager, cap) and torch.equal(eager, rep)
+    # ordering against NULL-stream work on both sides: inputs produced right before the call, output consumed right after
+    X2 = X * 1.0 + 0.0
+    out = (m(X2, t, Y) * 2.0).clone()
+    assert torch.equal(out, eager * 2.0)
+    # fused sampler: N graph launches per call
+    n0 = m.dnn.graph_launches()
+    a = get_white_box_solver("euler", m.ode, m, Y=Y, N=4, z=Z)()[0].clone()
+    assert m.dnn.graph_launches() - n0 == 4
+    # caller-owned side stream: captured directly on it
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        n0 = m.dnn.graph_launches()
+        b = get_white_box_solver("euler", m.ode, m, Y=Y, N=4, z=Z)()[0].clone()
+        assert m.dnn.graph_launches() - n0 == 4
+    side.synchronize()
+    assert torch.equal(a, b)
+    ref = get_white_box_solver("euler", m.ode, lambda xx, tt, yy: m(xx, tt, yy), Y=Y, N=4, z=Z)()[0]   # plugin loop
+    assert C.rel_l2(a.cpu(), ref.cpu()) < 1e-6
 
 
 @pytest.mark.timeout(900)
