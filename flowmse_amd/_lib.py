@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflowse_hip.so")
+# FLOWSE_LIB_PATH: load another build of the same library (A-B timing of kernel variants, tools/build_variants.py)
+LIB_PATH = os.environ.get("FLOWSE_LIB_PATH") or os.path.join(_HERE, "libflowse_hip.so")
 
 FLOWSE_MAX_LEVELS = 8
 FLOWSE_MAX_ATTN = 4

@@ -881,6 +881,22 @@ __device__ __forceinline__ float fast_silu(float x) { return x * __builtin_amdgc
 // fp32 VALU forms (v_pk_add / v_pk_fma / v_pk_mul); only v_exp_f32 / v_rcp_f32 stay scalar.  `keep` = 0 zeroes the
 // quad (halo pixel outside the image: zero padding applies AFTER the activation).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef FLOWSE_NOPK
+template <int GN>
+__device__ __forceinline__ u32x4 gn_quad(u32x4 raw, float4 mu, float4 sc, float4 be, bool keep) {
+    float v[4] = {__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)};
+    const float m[4] = {mu.x, mu.y, mu.z, mu.w}, s[4] = {sc.x, sc.y, sc.z, sc.w}, b[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = fmaf(v[e] - m[e], s[e], b[e]);
+        if (GN == 2) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v[e] * -1.44269504088896341f));
+    }
+    u32x4 o;
+    o.x = keep ? __float_as_uint(v[0]) : 0u; o.y = keep ? __float_as_uint(v[1]) : 0u;
+    o.z = keep ? __float_as_uint(v[2]) : 0u; o.w = keep ? __float_as_uint(v[3]) : 0u;
+    return o;
+}
+#else
 template <int GN>
 __device__ __forceinline__ u32x4 gn_quad(u32x4 raw, float4 mu, float4 sc, float4 be, bool keep) {
     f32x2 lo = {__uint_as_float(raw.x), __uint_as_float(raw.y)}, hi = {__uint_as_float(raw.z), __uint_as_float(raw.w)};
@@ -903,6 +919,8 @@ __device__ __forceinline__ u32x4 gn_quad(u32x4 raw, float4 mu, float4 sc, float4
     o.z = keep ? __float_as_uint(hi.x) : 0u; o.w = keep ? __float_as_uint(hi.y) : 0u;
     return o;
 }
+
+#endif
 
 #ifndef FLOWSE_HTAP
 #define FLOWSE_HTAP 1
@@ -1887,6 +1905,34 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     //                                v4 = (d4 - d2) - 2 (d3 - d1) -> D[2]
     // (float2 halves: hipcc emits the packed v_pk_add / v_pk_fma forms, half the VALU instructions)
 #define FLOWSE_H2(Q, H) (*reinterpret_cast<f32x2*>(&(Q).x + 2 * (H)))
+#ifdef FLOWSE_NOPK
+    // scalar fp32 forms: packed fp32 VALU (v_pk_fma_f32 / v_pk_add_f32) beside MFMAs costs more than the two scalar
+    // instructions it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+#define FLOWSE_E4(Q, I) (reinterpret_cast<float*>(&(Q))[I])
+#define FLOWSE_WXA(D)                                                                                                \
+    {                                                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+            const float r0 = FLOWSE_E4(D[0], e), r2 = FLOWSE_E4(D[2], e), r4 = FLOWSE_E4(D[4], e);                   \
+            const float v = fmaf(4.f, r0, fmaf(-5.f, r2, r4));                                                       \
+            if (CH == 0) FLOWSE_E4(D[0], e) = v;                                                                     \
+            else FLOWSE_E4(D[4], e) = v;                                                                             \
+        }                                                                                                            \
+    }
+#define FLOWSE_WXB(D)                                                                                                \
+    {                                                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+            const float r0 = FLOWSE_E4(D[0], e), r1 = FLOWSE_E4(D[1], e), r2 = FLOWSE_E4(D[2], e),                   \
+                        r3 = FLOWSE_E4(D[3], e), r4 = FLOWSE_E4(D[4], e);                                            \
+            if (CH == 0) {                                                                                           \
+                FLOWSE_E4(D[1], e) = fmaf(-4.f, r1 + r2, r3 + r4);                                                   \
+                FLOWSE_E4(D[2], e) = fmaf(4.f, r1 - r2, r4 - r3);                                                    \
+            } else {                                                                                                 \
+                FLOWSE_E4(D[1], e) = fmaf(2.f, r2 - r0, r3 - r1);                                                    \
+                FLOWSE_E4(D[2], e) = fmaf(-2.f, r2 - r0, r3 - r1);                                                   \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+#else
 #define FLOWSE_WXA(D)                                                                                                \
     {                                                                                                                \
         const f32x2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f};                                                             \
@@ -1912,6 +1958,7 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
             }                                                                                                        \
         }                                                                                                            \
     }
+#endif
     // operands: CH 0 -> D[0], D[1], D[2] = v0, v1, v2;  CH 1 -> D[4], D[1], D[2] = v5, v3, v4
 #define FLOWSE_WMMA3(V, BF, K)                                                                                       \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
@@ -1969,6 +2016,9 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
 #undef FLOWSE_WMMA3
 #undef FLOWSE_WPHASE
 #undef FLOWSE_FENCE
+#ifdef FLOWSE_E4
+#undef FLOWSE_E4
+#endif
     FLOWSE_TS_MARK(6)
 
     // This wave's half of A^T m, laid out like four 32-pixel tiles of the <2,2,2,1> epilogue: accumulator register

@@ -287,12 +287,12 @@ def test_black_box_solver_matches_oracle_vf(tiny):
     assert C.rel_l2(got.cpu(), ref) < 2e-3
 
 
-@pytest.mark.parametrize("mode,bound", [("fp32", 1e-4), ("bf16x3", 1e-4), ("bf16", 2e-2), ("fp16", 2.6e-3)])
+@pytest.mark.parametrize("mode,bound", [("fp32", 1e-4), ("bf16x3", 1e-4), ("bf16", 1.7e-2), ("fp16", 2.1e-3)])
 def test_precision_modes_vs_oracle(full, mode, bound):
     """Matrix-core operand modes of the large 3x3 convs at a shape that takes the LDS-halo kernels ([2,.,256,128]:
     512 pixel tiles), against the CPU oracle.  'bf16x3' (hi/lo split, 3 bf16 MFMAs per fp32 product) must stay
     fp32-class, far inside the 1e-3 bar; 'bf16' / 'fp16' (BASELINE configs 3 / 5) are held to 2x what MI355X runs
-    measure (1.0e-2 / 1.3e-3): a ceiling that an accuracy regression of the 16-bit kernels breaks."""
+    measure (8.5e-3 / 1.03e-3): a ceiling that an accuracy regression of the 16-bit kernels breaks."""
     from oracle import ncsnpp_oracle as O
     tb = C.param_tables()["full"]
     w = C.synth_weights(tb["names"], tb["shapes"])
@@ -311,12 +311,12 @@ def test_precision_modes_vs_oracle(full, mode, bound):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode,bound", [("bf16", 1e-2), ("fp16", 1.2e-3)])
+@pytest.mark.parametrize("mode,bound", [("bf16", 8e-3), ("fp16", 8e-4)])
 def test_16bit_sampler_vs_oracle(full, mode, bound):
     """BASELINE config 3 (bf16) / config 5 (fp16) arithmetic end to end: N = 5 Euler sampler at [2,1,256,128] with
     activations stored in 16 bits, against the fp32 CPU oracle.  The 1e-3 bar of north_star is stated for fp32; 16-bit
     storage over ~110 layers cannot meet it ('hard parts') -- the measured error is printed and bounded at
-    about 2x the measured value (bf16 ~5e-3, half ~6e-4), so a 10x accuracy regression cannot pass."""
+    about 2x the measured value (bf16 3.9e-3, half 3.9e-4), so a 10x accuracy regression cannot pass."""
     from flowmse_amd.sampling import get_white_box_solver
     from oracle import ncsnpp_oracle as O
     from oracle import sampler_oracle as S
