@@ -1743,7 +1743,168 @@ extern "C" int flowse_debug_ts(unsigned long long* host, int n) {
 // wave (wn, ch) owns output channels 32 wn .. +31 and the component half ch (0: m0..m2 from d0..d4, 1: m3..m5 from
 // d1..d5) -- 3 x 16 accumulators per lane.  The two halves of A^T m are added in the epilogue's LDS tile.  fp32
 // error of the 1-D F(4,3) form is ~3x the direct sum's (6e-7 vs 2e-7 rel-L2 on unit-variance data).
-constexpr int F43_HROW = 18 * LDS_ROW + 8;    // words per halo pixel row: 4 rows = 0 mod 64 banks (quad 1 vs quad 0)
+#ifndef FLOWSE_F43_EXCHANGE
+#define FLOWSE_F43_EXCHANGE 1            /* 0: the staged C-tile output stage of round 2 (A-B builds) */
+#endif
+constexpr int F43_HROW = 18 * LDS_ROW + 8;
+
+// ---- output stage of the 128-channel F(4,3) blocks (TN = 2): the two component halves of a channel group meet through
+// ONE wide LDS exchange instead of a read-modify-write pass over a block-wide C tile.
+//
+// Wave (wn, CH) holds, for its 64 channels (two 32-channel MFMA tiles j = 0, 1) and the 32 row quads of the pixel tile,
+// the Winograd components m0..m2 (CH 0) or m5, m3, m4 (CH 1).  out = A^T m needs both halves:
+//     o0 = (m0 + m1 + m2) + (m3 + m4)        o1 = (m1 - m2) + 2 (m3 - m4)
+//     o2 = (m1 + m2) + 4 (m3 + m4)           o3 = (m1 - m2) + 8 (m3 - m4) + m5
+// Each wave KEEPS tile j = CH and GIVES tile j = 1 - CH to its partner (same wn, other CH; identical lane -> (channel,
+// row quad) mapping) as three numbers per accumulator register -- CH 0: (m0 + m1 + m2, m1 - m2, m1 + m2), CH 1:
+// (m3 + m4, m3 - m4, m5) -- written as 12 conflict-free ds_write_b128 per lane ([wave][12][lane][4]); one barrier; 12
+// ds_read_b128 of the partner's region.  Afterwards every wave owns the FINISHED 32 channels x 128 pixels of one tile:
+// it transposes them through the region it has just read (nobody else touches it again) in two passes of 4 image rows
+// -- 32 ds_write_b32 + 8 ds_read_b128 per lane and pass, wave-private, no block barrier -- adds bias / per-sample bias /
+// residual, scales, stores 16-byte quads (128 contiguous bytes per pixel) and leaves the GroupNorm partial statistics of
+// its 32 channels over the whole tile (lane shuffles only: all 128 pixels of a channel live in ONE wave).
+// LDS: 4 x 12 KB (overlays the halo buffers; the caller's last loop iteration ended with a barrier).
+template <int CH>
+__device__ __forceinline__ void f43_out_exchange(const ConvArgs& a, f32x16 (&acc)[3][2], float* smem, int b, int y0, int x0,
+                                                 int n0, int tile) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1;
+    const int li = lane & 31, kh = lane >> 5;
+    constexpr int JG = 1 - CH, JK = CH;                  // tile given away / tile kept
+    float* Xmine = smem + wave * (12 * 256);             // [12][64 lanes][4]
+    float* Xpart = smem + (wave ^ 2) * (12 * 256);
+    const int W = a.W, Cout = a.Cout;
+    const int ch0 = n0 + wn * 64 + JK * 32;              // first of this wave's 32 finished channels
+    const int pl = lane >> 3, cq = lane & 7;             // row pass: pixel lane, channel quad
+    const bool has_res = a.res != nullptr;
+        const int64_t pix0 = ((int64_t)b * a.H + y0) * W + x0;
+    const float* resb = a.res + pix0 * Cout + ch0 + cq * 4;
+    float* outb = a.out + pix0 * Cout + ch0 + cq * 4;
+    int roff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int pp = i * 8 + pl;                       // pixel of a 4 x 16 pass, row-major
+        roff[i] = ((pp >> 4) * W + (pp & 15)) * Cout;
+    }
+    float4 rres[2][8];                                   // both passes' residual quads: requested now, in flight during the exchange
+    if (has_res) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                rres[pass][i] = *reinterpret_cast<const float4*>(resb + pass * 4 * W * Cout + roff[i]);
+    }
+    // ---- give
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 v0, v1, v2;
+        float* e0 = &v0.x; float* e1 = &v1.x; float* e2 = &v2.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            if (CH == 0) {
+                const float s12 = acc[1][JG][r] + acc[2][JG][r];
+                e0[e] = acc[0][JG][r] + s12;
+                e1[e] = acc[1][JG][r] - acc[2][JG][r];
+                e2[e] = s12;
+            } else {                                     // acc[0] = m5, acc[1] = m3, acc[2] = m4
+                e0[e] = acc[1][JG][r] + acc[2][JG][r];
+                e1[e] = acc[1][JG][r] - acc[2][JG][r];
+                e2[e] = acc[0][JG][r];
+            }
+        }
+        *reinterpret_cast<float4*>(Xmine + ((0 * 4 + g) * 64 + lane) * 4) = v0;
+        *reinterpret_cast<float4*>(Xmine + ((1 * 4 + g) * 64 + lane) * 4) = v1;
+        *reinterpret_cast<float4*>(Xmine + ((2 * 4 + g) * 64 + lane) * 4) = v2;
+    }
+    __syncthreads();
+    // ---- take: o[k][r] = finished output row k of accumulator register r (tile JK)
+    float o[4][16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 t0 = *reinterpret_cast<const float4*>(Xpart + ((0 * 4 + g) * 64 + lane) * 4);
+        const float4 t1 = *reinterpret_cast<const float4*>(Xpart + ((1 * 4 + g) * 64 + lane) * 4);
+        const float4 t2 = *reinterpret_cast<const float4*>(Xpart + ((2 * 4 + g) * 64 + lane) * 4);
+        const float* q0 = &t0.x; const float* q1 = &t1.x; const float* q2 = &t2.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            if (CH == 0) {                               // own m0..m2; received s34, d34, m5
+                const float s12 = acc[1][JK][r] + acc[2][JK][r], d12 = acc[1][JK][r] - acc[2][JK][r];
+                o[0][r] = (acc[0][JK][r] + s12) + q0[e];
+                o[1][r] = fmaf(2.f, q1[e], d12);
+                o[2][r] = fmaf(4.f, q0[e], s12);
+                o[3][r] = fmaf(8.f, q1[e], d12) + q2[e];
+            } else {                                     // own m5, m3, m4; received m0+m1+m2, m1-m2, m1+m2
+                const float s34 = acc[1][JK][r] + acc[2][JK][r], d34 = acc[1][JK][r] - acc[2][JK][r];
+                o[0][r] = q0[e] + s34;
+                o[1][r] = fmaf(2.f, d34, q1[e]);
+                o[2][r] = fmaf(4.f, s34, q2[e]);
+                o[3][r] = fmaf(8.f, d34, q1[e]) + acc[0][JK][r];
+            }
+        }
+    }
+    // ---- transpose through the region just read (wave-private from here on), finish, store, statistics
+    float* T = Xpart;                                    // [64 pixels][32 channels] per pass
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + ch0 + cq * 4);
+    if (a.bias2) {
+        const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)b * a.bias2_stride + ch0 + cq * 4);
+        bq.x += t.x; bq.y += t.y; bq.z += t.z; bq.w += t.w;
+    }
+    const float scale = a.scale;
+    float4 piv = make_float4(0.f, 0.f, 0.f, 0.f), s1 = piv, s2 = piv;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {               // pass = row quad of the tile: image rows 4 pass .. 4 pass + 3
+        if (pass == 1) __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave: pass 0's reads precede these writes
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * pass + e;              // registers of this row quad; tile column (e & 3) + 8 (e >> 2) + 4 kh
+                T[(k * 16 + (e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + li] = o[k][r];
+            }
+        __builtin_amdgcn_wave_barrier();                 // in-order LDS: the tile is complete for this wave's reads
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pp = i * 8 + pl;
+            float4 v = *reinterpret_cast<const float4*>(T + pp * 32 + cq * 4);
+            v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+            if (has_res) { v.x += rres[pass][i].x; v.y += rres[pass][i].y; v.z += rres[pass][i].z; v.w += rres[pass][i].w; }
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            *reinterpret_cast<float4*>(outb + pass * 4 * W * Cout + roff[i]) = v;
+            if (pass == 0 && i == 0) piv = v;
+            const float dx = v.x - piv.x, dy = v.y - piv.y, dz = v.z - piv.z, dw = v.w - piv.w;
+            s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+            s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
+        }
+    }
+    if (!a.stats) return;
+    // 16 values per lane and channel -> the 8 pixel lanes of a channel quad (equal-count Chan merges) -> 128 pixels
+    float mean[4] = {piv.x + s1.x * (1.f / 16), piv.y + s1.y * (1.f / 16), piv.z + s1.z * (1.f / 16), piv.w + s1.w * (1.f / 16)};
+    float m2[4] = {fmaxf(s2.x - s1.x * s1.x * (1.f / 16), 0.f), fmaxf(s2.y - s1.y * s1.y * (1.f / 16), 0.f),
+                   fmaxf(s2.z - s1.z * s1.z * (1.f / 16), 0.f), fmaxf(s2.w - s1.w * s1.w * (1.f / 16), 0.f)};
+    float cnt = 16.f;
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float mo = __shfl_xor(mean[j], off), qo = __shfl_xor(m2[j], off);
+            const float d = mo - mean[j];
+            m2[j] = m2[j] + qo + d * d * (0.5f * cnt);
+            mean[j] = 0.5f * (mean[j] + mo);
+        }
+        cnt *= 2.f;
+    }
+    if (pl == 0) {
+        float* dst = a.stats + (((int64_t)b * a.stats_nblk + tile) * Cout + ch0 + cq * 4) * 2;
+        *reinterpret_cast<float4*>(dst) = make_float4(mean[0], m2[0], mean[1], m2[1]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(mean[2], m2[2], mean[3], m2[3]);
+    }
+}
+
+    // words per halo pixel row: 4 rows = 0 mod 64 banks (quad 1 vs quad 0)
 
 template <int GN, int CH, bool SPLIT, int TN>
 __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem) {
@@ -1835,7 +1996,9 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
         if (h == 0) gparams(chunk);
     };
     auto xform1 = [&](int Q) {
+#ifndef FLOWSE_PROBE_NOGN
         if (GN) rh[Q % 3] = gn_quad<GN>(rh[Q % 3], g_mu, g_sc, g_be, (hin >> Q) & 1u);
+#endif
     };
     auto lstoreH = [&](int buf, int h) {
         float* Hb = Hs + buf * HBUF;
@@ -1905,7 +2068,10 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     //                                v4 = (d4 - d2) - 2 (d3 - d1) -> D[2]
     // (float2 halves: hipcc emits the packed v_pk_add / v_pk_fma forms, half the VALU instructions)
 #define FLOWSE_H2(Q, H) (*reinterpret_cast<f32x2*>(&(Q).x + 2 * (H)))
-#ifdef FLOWSE_NOPK
+#if defined(FLOWSE_PROBE_NOXFORM)      /* measurement probe: no input transform (results are garbage, timing what-if) */
+#define FLOWSE_WXA(D)
+#define FLOWSE_WXB(D)
+#elif defined(FLOWSE_NOPK)
     // scalar fp32 forms: packed fp32 VALU (v_pk_fma_f32 / v_pk_add_f32) beside MFMAs costs more than the two scalar
     // instructions it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
 #define FLOWSE_E4(Q, I) (reinterpret_cast<float*>(&(Q))[I])
@@ -2059,9 +2225,25 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
             if (pass == 0) __syncthreads();
         }
     };
+#ifdef FLOWSE_PROBE_NOEPI       /* measurement probe: no output stage (keeps the accumulators alive; results are garbage) */
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[c][j][r];
+        if (t == 12345.678f) a.out[m_tl] = t;
+        return;
+    }
+#endif
     if constexpr (SPLIT) {                               // split slices: raw partial tiles through the shared epilogue
         conv_epilogue_with<2, 2, 2, 1>(a, smem, m_tl, n0, M, HW, (int)blockIdx.y, W,
                                        [&](float* Cs, int CROW) { scatter_half(Cs, CROW, 0); });
+    } else if constexpr (TN == 2 && FLOWSE_F43_EXCHANGE) {
+        const int tile_ix = ty * tiles_x + tx;           // row-major index of this 8 x 16 tile in the sample's tile grid
+        f43_out_exchange<CH>(a, acc, smem, b, y0, x0, n0, tile_ix);
     } else {
         // C tile of all 64 TN channels ([128][64 TN + 4] floats): with TN = 2 both channel groups scatter at once (two
         // waves per pass instead of one), then the output stage runs over the two 64-channel halves back to back
