@@ -52,6 +52,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC = 32;          // channels per K step
 constexpr int LDS_ROW = 36;     // floats per LDS tile row (KC + 4 pad)
+bool conv_small_m(int64_t M, int Cout);
+bool conv_splitk_in_launch();
 
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with its own
 // L2); remapping so that every XCD walks a CONTIGUOUS range of tiles keeps the rows shared by vertically
@@ -139,6 +141,7 @@ __device__ __forceinline__ void conv_epilogue_with(const ConvArgs& a, float* sme
         // acquires, sums the slices 0 .. ks-1 in that order (its own included, re-read: the sum is independent of which
         // slice arrived last), applies bias / per-sample bias / residual / scale, stores, and leaves the GroupNorm
         // partial statistics of what it stored -- exactly the layouts the two-pass reduction kernels write.
+        if constexpr (BM != 128) return;       // (the in-launch form is written for 128-row tiles; launch_conv never pairs it with others)
         __threadfence();
         __syncthreads();
         int* flag = reinterpret_cast<int*>(smem);            // the C tile is free again
@@ -153,7 +156,6 @@ __device__ __forceinline__ void conv_epilogue_with(const ConvArgs& a, float* sme
         if (!last) return;
         __threadfence();
         __syncthreads();                                     // everyone has read the flag: Cs may be overwritten
-        static_assert(BM == 128, "tile rows");
         const int ks = (int)gridDim.y;
         const int64_t slice = (int64_t)M * a.Cout;
         if (ncol) {
@@ -756,9 +758,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
     const __amdgpu_buffer_rsrc_t rsrcw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.Cout * taps * Cin * 4, 0x00020000);
 
-    u32x4 ra[A_LOADS], rb[B_LOADS];
+    // Operand staging: registers -> LDS, double-buffered in LDS AND two steps deep in registers.  The A rows of a 1x1
+    // shortcut at 256 x 256 come straight from HBM (first touch of the block's pixels; 2-4 us loaded latency) while one K
+    // step is only 64 MFMAs per wave = 1.7 us: requested ONE step ahead (round 2) they were waited for at every step;
+    // requested TWO steps ahead they have a full step of slack.  The register ring index is a compile-time constant
+    // (the loop is unrolled by two), so nothing is indexed dynamically.
+    u32x4 ra[2][A_LOADS], rb[2][B_LOADS];
 
-    auto gload = [&](int s) {
+    auto gload = [&](int s, auto ring) {
+        constexpr int R = decltype(ring)::value;
         const int chunk = s / taps, tap = s - chunk * taps;
         int shift = W + 1;                                    // window origin is pixel m0 - W - 1
         if (taps == 9) shift += (tap / 3 - 1) * W + (tap - (tap / 3) * 3 - 1);
@@ -770,21 +778,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
         for (int q = 0; q < A_LOADS; ++q) {
             const bool ok = (tapmask[q] >> tap) & 1u;
             const unsigned vo = ok ? (second ? avo2[q] : avo1[q]) : OOB;
-            ra[q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, vo, soff_a, 0)
-                           : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, vo, soff_a, 0);
+            ra[R][q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, vo, soff_a, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, vo, soff_a, 0);
         }
 #pragma unroll
-        for (int q = 0; q < B_LOADS; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo[q], soff_b, 0);
+        for (int q = 0; q < B_LOADS; ++q) rb[R][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo[q], soff_b, 0);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, auto ring) {
+        constexpr int R = decltype(ring)::value;
         float* Ab = As + buf * BM * LDS_ROW;
         float* Bb = Bs + buf * BN * LDS_ROW;
 #pragma unroll
         for (int q = 0; q < A_LOADS; ++q)
-            *reinterpret_cast<u32x4*>(Ab + (row0 + 32 * q) * LDS_ROW + col4 * 4) = ra[q];
+            *reinterpret_cast<u32x4*>(Ab + (row0 + 32 * q) * LDS_ROW + col4 * 4) = ra[R][q];
 #pragma unroll
         for (int q = 0; q < B_LOADS; ++q)
-            *reinterpret_cast<u32x4*>(Bb + (row0 + 32 * q) * LDS_ROW + col4 * 4) = rb[q];
+            *reinterpret_cast<u32x4*>(Bb + (row0 + 32 * q) * LDS_ROW + col4 * 4) = rb[R][q];
     };
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -804,13 +813,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
     const int s_begin = split * per;
     const int S = min(S_all, s_begin + per);
 
-    gload(s_begin);
-    lstore(0);
-    __syncthreads();
-
-    for (int s = s_begin; s < S; ++s) {
-        const int buf = (s - s_begin) & 1;
-        if (s + 1 < S) gload(s + 1);
+    auto compute = [&](int buf) {
         const float* Ab = As + buf * BM * LDS_ROW + (wm * TM * 32 + li) * LDS_ROW + kh * 4;
         const float* Bb = Bs + buf * BN * LDS_ROW + (wn * TN * 32 + li) * LDS_ROW + kh * 4;
 #pragma unroll
@@ -833,7 +836,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < S) lstore(buf ^ 1);
+    };
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+
+    gload(s_begin, R0{});
+    if (s_begin + 1 < S) gload(s_begin + 1, R1{});
+    lstore(0, R0{});
+    __syncthreads();
+
+    for (int s = s_begin; s < S; s += 2) {
+        // step s: LDS buffer 0; ring 0 is free (stored), ring 1 holds step s + 1
+        if (s + 2 < S) gload(s + 2, R0{});
+        compute(0);
+        if (s + 1 < S) lstore(1, R1{});
+        __syncthreads();
+        if (s + 1 >= S) break;
+        // step s + 1: LDS buffer 1; ring 1 is free, ring 0 holds step s + 2
+        if (s + 3 < S) gload(s + 3, R1{});
+        compute(1);
+        if (s + 2 < S) lstore(0, R0{});
         __syncthreads();
     }
     conv_epilogue<WM, WN, TM, TN, OT>(a, acc, smem, m0, n0, M, HW, split);
@@ -1282,7 +1304,8 @@ int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     if (conv_supports_head4(B, H, W, Cin, 0, Cout, taps)) return 1;     // 4-channel heads: dedicated kernel
     const int64_t M = (int64_t)B * H * W;
     const int bn = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;       // N tile launch_conv picks for this width
-    const int64_t tiles = ((M + 127) / 128) * ((Cout + bn - 1) / bn);
+    const int bm = conv_small_m(M, Cout) ? 32 : 128;              // M tile (single utterances at the 8x8 / 4x4 levels: 32 rows)
+    const int64_t tiles = ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
     const int steps = ((Cin + KC - 1) / KC) * taps;
     if (tiles >= 256 || steps < 8) return 1;          // measured: 256 beats 128 and 64 at B = 1..8
     const int wp = wino_plan(B, H, W, Cin, Cout, taps);
@@ -1296,6 +1319,11 @@ int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     ks = (steps + per - 1) / per;
     return (int)ks;
 }
+
+// Images with at most 64 pixels in the whole batch (one utterance at the 8x8 and 4x4 levels): a 128-row tile would spend
+// 50-87 % of its MFMAs on padding rows and every K step costs 64 MFMAs per wave whatever M is.  They run 32-row tiles
+// (4 waves side by side along N, 16 MFMAs per wave and step) and are sliced along K accordingly.
+bool conv_small_m(int64_t M, int Cout) { return M <= 64 && Cout > 64 && !conv_splitk_in_launch(); }   // (that form: 128-row tiles only)
 
 bool conv_splitk_is_wino(int B, int H, int W, int Cin, int Cout, int taps) {
     return conv_wino_default_f43() && conv_supports_wino(B, H, W, Cin, 0, Cout, taps) && wino_plan(B, H, W, Cin, Cout, taps) >= 2;
@@ -1787,13 +1815,12 @@ __device__ __forceinline__ void f43_out_exchange(const ConvArgs& a, f32x16 (&acc
         const int pp = i * 8 + pl;                       // pixel of a 4 x 16 pass, row-major
         roff[i] = ((pp >> 4) * W + (pp & 15)) * Cout;
     }
-    float4 rres[2][8];                                   // both passes' residual quads: requested now, in flight during the exchange
+    // residual quads: the first pass's are requested now (in flight during the exchange), the second pass's as soon as
+    // the accumulators are dead (in flight during the first pass) -- never more than the registers the loop state leaves
+    float4 rres[2][8];
     if (has_res) {
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                rres[pass][i] = *reinterpret_cast<const float4*>(resb + pass * 4 * W * Cout + roff[i]);
+        for (int i = 0; i < 8; ++i) rres[0][i] = *reinterpret_cast<const float4*>(resb + roff[i]);
     }
     // ---- give
 #pragma unroll
@@ -1844,6 +1871,10 @@ __device__ __forceinline__ void f43_out_exchange(const ConvArgs& a, f32x16 (&acc
                 o[3][r] = fmaf(8.f, d34, q1[e]) + acc[0][JK][r];
             }
         }
+    }
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rres[1][i] = *reinterpret_cast<const float4*>(resb + 4 * W * Cout + roff[i]);
     }
     // ---- transpose through the region just read (wave-private from here on), finish, store, statistics
     float* T = Xpart;                                    // [64 pixels][32 channels] per pass
@@ -1906,8 +1937,17 @@ __device__ __forceinline__ void f43_out_exchange(const ConvArgs& a, f32x16 (&acc
 
     // words per halo pixel row: 4 rows = 0 mod 64 banks (quad 1 vs quad 0)
 
+// Per-tile state of the staging pipeline: which pixels of the 10 x 18 halo lie inside the image and the window
+// descriptors of the two source tensors.  A block that owns several tiles (tpb > 1) keeps the state of the tile it
+// computes and of the one it stages for.
+struct F43Tile {
+    int y0, x0, ty, tx;
+    unsigned hin;                                        // bit q: this thread's halo quad q lies inside the image
+    unsigned woff;                                       // pixel offset of the tile's window inside the sample's descriptor
+};
+
 template <int GN, int CH, bool SPLIT, int TN>
-__device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem) {
+__device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem, int tpb) {
     static_assert(TN == 1 || !SPLIT, "the sliced form keeps the 64-channel block");
     constexpr int BN = 64 * TN;                          // TN 32-channel tiles per wave, two channel groups (wn) per block
     constexpr int HROWS = 180;                           // 10 x 18 halo pixels
@@ -1927,44 +1967,61 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
     const int n_ntiles = a.Cout / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
+    // a block owns `tpb` consecutive pixel tiles (in walk order) of ONE channel block
+    const int mg = bid / n_ntiles, nt = bid - mg * n_ntiles;
     const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 3);
-    const int b = mt / tiles_img, tt = mt - b * tiles_img;
-    // Tiles of an image are walked in vertical strips of 4 tiles (64 pixels), top to bottom: the rows a tile shares
-    // with its vertical neighbour are re-read 4 tiles later instead of a full tile row later, which keeps that window
-    // plus the streamed weights inside the 4 MB L2 of the XCD for 256-channel layers (2.3x -> ~1.1x HBM reads).
-    int ty, tx;
-    if ((tiles_x & 3) == 0) {
-        const int per_strip = 4 * (H >> 3);
-        const int strip = tt / per_strip, w = tt - strip * per_strip;
-        ty = w >> 2;
-        tx = strip * 4 + (w & 3);
-    } else {
-        ty = tt / tiles_x;
-        tx = tt - ty * tiles_x;
-    }
-    const int y0 = ty * 8, x0 = tx * 16, n0 = nt * BN;
-    const int m_tl = (b * H + y0) * W + x0;
-
+    const int n0 = nt * BN;
     const int col4 = tid & 7, row0 = tid >> 3;
     unsigned hpix[H_LOADS];                              // pixel offset of this thread's halo quads in the window
     int hlds[H_LOADS];                                   // their LDS word offset (-1: past the last halo pixel)
-    unsigned hin = 0;                                    // bit q: quad q lies inside the image
 #pragma unroll
     for (int q = 0; q < H_LOADS; ++q) {
         const int hr = row0 + 32 * q;
         const int hy = hr / 18, hx = hr - hy * 18;
-        const bool in = hr < HROWS && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
         hpix[q] = (unsigned)(hy * W + hx);
         hlds[q] = hr < HROWS ? hy * F43_HROW + hx * LDS_ROW + col4 * 4 : -1;
-        hin |= in ? (1u << q) : 0u;
     }
-    const int64_t wbase = (int64_t)m_tl - W - 1;
     const int wpix = 9 * W + 18;
+    // Tiles of an image are walked in vertical strips of 4 tiles (64 pixels), top to bottom: the rows a tile shares
+    // with its vertical neighbour are re-read 4 tiles later instead of a full tile row later, which keeps that window
+    // plus the streamed weights inside the 4 MB L2 of the XCD for 256-channel layers (2.3x -> ~1.1x HBM reads).
+    // All tiles of a block lie in ONE sample (launch_f43: tiles per block divides the tiles of an image), so the two source
+    // descriptors are per block -- base = the sample's pixel (-W - 1), i.e. the window origin of its first tile -- and a
+    // tile only contributes the scalar offset of its window (no per-tile descriptor state in registers).
+    const int bsmp = (mg * tpb) / tiles_img;
+    const int b = bsmp;
+    const int64_t sbase = (int64_t)bsmp * HW - W - 1;
+    const int spix = HW + 2 * W + 2;
     const __amdgpu_buffer_rsrc_t rsrc1 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1 + wbase * C1), 0, wpix * C1 * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1 + sbase * C1), 0, spix * C1 * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(C2 ? a.in2 + wbase * C2 : a.in1), 0, C2 ? wpix * C2 * 4 : 0, 0x00020000);
+        const_cast<float*>(C2 ? a.in2 + sbase * C2 : a.in1), 0, C2 ? spix * C2 * 4 : 0, 0x00020000);
+    auto make_tile = [&](int mt) {
+        F43Tile t;
+        const int tt = mt - bsmp * tiles_img;
+        if ((tiles_x & 3) == 0) {
+            const int per_strip = 4 * (H >> 3);
+            const int strip = tt / per_strip, w = tt - strip * per_strip;
+            t.ty = w >> 2;
+            t.tx = strip * 4 + (w & 3);
+        } else {
+            t.ty = tt / tiles_x;
+            t.tx = tt - t.ty * tiles_x;
+        }
+        t.y0 = t.ty * 8;
+        t.x0 = t.tx * 16;
+        t.hin = 0;
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            const int hr = row0 + 32 * q;
+            const int hy = hr / 18, hx = hr - hy * 18;
+            const bool in = hr < HROWS && (unsigned)(t.y0 - 1 + hy) < (unsigned)H && (unsigned)(t.x0 - 1 + hx) < (unsigned)W;
+            t.hin |= in ? (1u << q) : 0u;
+        }
+        t.woff = (unsigned)(t.y0 * W + t.x0);
+        return t;
+    };
+    F43Tile cur = make_tile(mg * tpb);
     const __amdgpu_buffer_rsrc_t rsrcw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wino), 0, a.Cout * 18 * Cin * 4, 0x00020000);
 
@@ -1972,17 +2029,18 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     // LDS write into the idle buffer), so that only 12 staging registers are live at any time
     u32x4 rh[3];
     float4 g_mu, g_sc, g_be;
+    unsigned st_hin = cur.hin;                           // halo mask of the tile being STAGED (cur, or the block's next tile)
 
-    auto hload = [&](int chunk, int Q) -> u32x4 {
+    auto hload = [&](const F43Tile& t, int chunk, int Q) -> u32x4 {
         const int c0 = chunk * KC;
         const bool second = c0 >= C1;
-        const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * 4u;
         const unsigned cs = (unsigned)(second ? C2 : C1);
-        const unsigned off = ((hin >> Q) & 1u) ? (hpix[Q] * cs + (unsigned)col4 * 4u) * 4u : OOB;
+        const unsigned soff = (t.woff * cs + (unsigned)(second ? c0 - C1 : c0)) * 4u;
+        const unsigned off = ((t.hin >> Q) & 1u) ? (hpix[Q] * cs + (unsigned)col4 * 4u) * 4u : OOB;
         return second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, soff, 0)
                       : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, soff, 0);
     };
-    auto gparams = [&](int chunk) {
+    auto gparams = [&](const F43Tile& t, int chunk) {
         if (GN) {
             const int cg = chunk * KC + col4 * 4;
             g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
@@ -1990,14 +2048,17 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
             g_be = *reinterpret_cast<const float4*>(a.gn.beta + cg);
         }
     };
-    auto gloadH = [&](int chunk, int h) {
+    auto gloadH = [&](const F43Tile& t, int chunk, int h) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) rh[q] = hload(chunk, 3 * h + q);
-        if (h == 0) gparams(chunk);
+        for (int q = 0; q < 3; ++q) rh[q] = hload(t, chunk, 3 * h + q);
+        if (h == 0) {
+            gparams(t, chunk);
+            st_hin = t.hin;
+        }
     };
     auto xform1 = [&](int Q) {
 #ifndef FLOWSE_PROBE_NOGN
-        if (GN) rh[Q % 3] = gn_quad<GN>(rh[Q % 3], g_mu, g_sc, g_be, (hin >> Q) & 1u);
+        if (GN) rh[Q % 3] = gn_quad<GN>(rh[Q % 3], g_mu, g_sc, g_be, (st_hin >> Q) & 1u);
 #endif
     };
     auto lstoreH = [&](int buf, int h) {
@@ -2022,21 +2083,15 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
     const unsigned wvo = (unsigned)lane * 16u + (unsigned)CH * 3u * 4096u;
 
     f32x16 acc[3][TN];                                   // this wave's three Winograd components x TN channel tiles
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
 
-    {   // first chunk: all six quads at once (the accumulators are not live yet)
+    {   // first chunk of the block's first tile: all six quads at once (the accumulators are not live yet)
         u32x4 t[H_LOADS];
 #pragma unroll
-        for (int q = 0; q < H_LOADS; ++q) t[q] = hload(c_begin, q);
-        gparams(c_begin);
+        for (int q = 0; q < H_LOADS; ++q) t[q] = hload(cur, c_begin, q);
+        gparams(cur, c_begin);
 #pragma unroll
         for (int q = 0; q < H_LOADS; ++q) {
-            if (GN) t[q] = gn_quad<GN>(t[q], g_mu, g_sc, g_be, (hin >> q) & 1u);
+            if (GN) t[q] = gn_quad<GN>(t[q], g_mu, g_sc, g_be, (cur.hin >> q) & 1u);
             if (hlds[q] >= 0) *reinterpret_cast<u32x4*>(Hs + hlds[q]) = t[q];
         }
     }
@@ -2145,10 +2200,28 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
         (void)chunk;
         FLOWSE_WLOADB(0, 0, c_begin, bA)
     }
+    // ---- tiles of this block.  The staging pipeline runs ACROSS tile boundaries: during a tile's last chunk the halo of
+    // the NEXT tile's first chunk (and its first weight fragments) are requested, normalised and written to the idle LDS
+    // buffer exactly like any other "next chunk", so only the block's first tile pays a prologue (tpb > 1 needs an even
+    // number of chunks: every tile then starts in buffer 0, and the output stage lives behind it, see launch_f43).
+    for (int ti = 0; ti < tpb; ++ti) {
+    const bool more = ti + 1 < tpb;
+    const F43Tile nxt = more ? make_tile(mg * tpb + ti + 1) : cur;
+    const int y0 = cur.y0, x0 = cur.x0, ty = cur.ty, tx = cur.tx;
+    const int m_tl = (b * H + y0) * W + x0;
+    (void)ty; (void)tx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         const float* Hcur = Hs + ((chunk - c_begin) & 1) * HBUF;
-        const int cnext = min(chunk + 1, c_end - 1), nbuf = (chunk - c_begin + 1) & 1;
-        gloadH(cnext, 0);                                // next chunk's halo, first half
+        const bool wrap = chunk + 1 >= c_end;            // the tile's last chunk stages for the block's next tile
+        const int cnext = wrap ? (more ? c_begin : c_end - 1) : chunk + 1, nbuf = (chunk - c_begin + 1) & 1;
+        const F43Tile& stile = (wrap && more) ? nxt : cur;
+        gloadH(stile, cnext, 0);                         // next chunk's halo, first half
         FLOWSE_WLOADA(0, 0, dA)
         FLOWSE_WXA(dA) FLOWSE_WXB(dA)
         FLOWSE_FENCE
@@ -2157,7 +2230,7 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
         FLOWSE_WPHASE(dA, bA, 0, 3, chunk, dB, bB, 1)
         FLOWSE_WPHASE(dB, bB, 1, 0, chunk, dA, bA, 2)
         lstoreH(nbuf, 0);                                // the idle buffer: nobody reads it during this chunk
-        gloadH(cnext, 1);                                // second half
+        gloadH(stile, cnext, 1);                         // second half
         FLOWSE_FENCE
         FLOWSE_WPHASE(dA, bA, 1, 1, chunk, dB, bB, -1)
         FLOWSE_WPHASE(dB, bB, 1, 2, chunk, dA, bA, 3)
@@ -2243,7 +2316,9 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
                                        [&](float* Cs, int CROW) { scatter_half(Cs, CROW, 0); });
     } else if constexpr (TN == 2 && FLOWSE_F43_EXCHANGE) {
         const int tile_ix = ty * tiles_x + tx;           // row-major index of this 8 x 16 tile in the sample's tile grid
-        f43_out_exchange<CH>(a, acc, smem, b, y0, x0, n0, tile_ix);
+        // the exchange region sits BEHIND halo buffer 0, which already holds the next tile's first chunk (tpb > 1)
+        f43_out_exchange<CH>(a, acc, smem + HBUF, b, y0, x0, n0, tile_ix);
+        if (more) __syncthreads();                       // buffer 1 (under the exchange region) is written again in the next tile
     } else {
         // C tile of all 64 TN channels ([128][64 TN + 4] floats): with TN = 2 both channel groups scatter at once (two
         // waves per pass instead of one), then the output stage runs over the two 64-channel halves back to back
@@ -2279,6 +2354,8 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
         }
     }
 #endif
+    cur = nxt;
+    }   // tiles of this block
 }
 
 // SPLIT: the launch is sliced over chunks (gridDim.y > 1) and every block leaves a raw partial tile
@@ -2287,11 +2364,12 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem)
 // read feeds twice the MFMAs -- the VALU work per MFMA, which is what holds the matrix pipe below 0.75 in the TN = 1 form
 // (three waves of a SIMD issue ~2 VALU per 64-cycle MFMA), halves.
 template <int GN, bool SPLIT = false, int TN = 1>
-__global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv3x3_f43_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv3x3_f43_kernel(ConvArgs a, int tpb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (SPLIT || TN == 1) tpb = 1;                       // only the 128-channel whole-K form owns several tiles per block
     // waves 0,1: component half 0; waves 2,3: half 1.  Both bodies execute the same barriers.
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7)) conv3x3_f43_body<GN, 1, SPLIT, TN>(a, smem);
-    else conv3x3_f43_body<GN, 0, SPLIT, TN>(a, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7)) conv3x3_f43_body<GN, 1, SPLIT, TN>(a, smem, tpb);
+    else conv3x3_f43_body<GN, 0, SPLIT, TN>(a, smem, tpb);
 }
 
 // [Cout][9][Cin] -> fragment order [Cout/32][kx][Cin/32][component 0..5][k-block j][lane][4]; stored component order:
@@ -2336,6 +2414,10 @@ bool conv_f43_forced_bn64() {
     static const bool bn64 = getenv("FLOWSE_F43_BN64") != nullptr;
     return bn64;
 }
+static bool f43_single_tile() {      // FLOWSE_F43_TPB1=1: one tile per block everywhere (A-B hook)
+    static const bool one = getenv("FLOWSE_F43_TPB1") != nullptr;
+    return one;
+}
 bool conv_f43_wide(int B, int H, int W, int Cout) {
     return !conv_f43_forced_bn64() && (Cout % 128) == 0 && ((int64_t)B * H * W / 128) * (Cout / 128) >= 512;
 }
@@ -2344,15 +2426,28 @@ static int launch_f43(const ConvArgs& a, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int ks = a.ksplit > 1 ? a.ksplit : 1;       // slices of 32-channel chunks (gridDim.y), see wino_plan
     const bool wide = !a.partial && conv_f43_wide(a.B, a.H, a.W, a.Cout);
-    const int grid = (int)(M / 128) * (a.Cout / (wide ? 128 : 64));
+    // Tiles per block of the 128-channel form: as many (4, 2) as still leave two full rounds of 512 blocks (256 CUs x 2),
+    // so that the prologue -- first halo from HBM, its GroupNorm, first weights, ~14 % of a one-tile block's life -- is
+    // paid once per block instead of once per tile.  Needs an even chunk count (every tile starts in halo buffer 0).
+    int tpb = 1;
+    if (wide && FLOWSE_F43_EXCHANGE && (((a.C1 + a.C2) / KC) & 1) == 0 && !f43_single_tile()) {
+        const int64_t blocks1 = (M / 128) * (a.Cout / 128);
+        for (int t = 4; t >= 2; t >>= 1)
+            if (((int64_t)a.H * a.W / 128) % t == 0 && blocks1 / t >= 1024) { tpb = t; break; }
+    }
+    const int grid = (int)(M / 128 / tpb) * (a.Cout / (wide ? 128 : 64));
     const size_t lds_halo = 2 * 10 * F43_HROW * sizeof(float);         // two halo buffers; > the 64-channel C tile
+#if FLOWSE_F43_EXCHANGE
+    const size_t lds_c = (10 * F43_HROW + 4 * 12 * 256) * sizeof(float);   // halo buffer 0 + the exchange region of the output stage
+#else
     const size_t lds_c = ((size_t)128 * (64 * 2 + 4) + 4 * 64 * 2) * sizeof(float);   // the 128-channel C tile + statistics scratch
+#endif
     const size_t lds = wide && lds_c > lds_halo ? lds_c : lds_halo;
     const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;
 #define FLOWSE_LF43(G, SP, TNV)                                                                              \
     {                                                                                                        \
         if (const int rc = allow_lds<&conv3x3_f43_kernel<G, SP, TNV>>(lds)) return rc;                       \
-        hipLaunchKernelGGL((conv3x3_f43_kernel<G, SP, TNV>), dim3(grid, ks), dim3(256), lds, s, a);          \
+        hipLaunchKernelGGL((conv3x3_f43_kernel<G, SP, TNV>), dim3(grid, ks), dim3(256), lds, s, a, tpb);          \
     }
     if (a.partial) {
         if (gn == 2) FLOWSE_LF43(2, true, 1) else if (gn == 1) FLOWSE_LF43(1, true, 1) else FLOWSE_LF43(0, true, 1)
@@ -2374,7 +2469,9 @@ bool conv_wino_default_f43() {
 
 bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps) {
     return !g_no_wino && (Cout % 64) == 0 && conv_supports_fused_gn(B, H, W, C1, C2, Cout, taps) &&
-           wino_plan(B, H, W, C1 + C2, Cout, taps) >= 1 && (int64_t)Cout * 18 * (C1 + C2) * 4 < (1LL << 31);
+           wino_plan(B, H, W, C1 + C2, Cout, taps) >= 1 && (int64_t)Cout * 18 * (C1 + C2) * 4 < (1LL << 31) &&
+           // the F(4,3) kernel addresses a whole sample through one buffer descriptor per source tensor
+           ((int64_t)H * W + 2 * W + 2) * (C1 > C2 ? C1 : C2) * 4 < (1LL << 31);
 }
 
 static int launch_wino(const ConvArgs& a, hipStream_t s) {
@@ -3415,7 +3512,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
         return ERR_ARG;
     }
     const int rc = a.Cout <= 32 ? launch_cfg<4, 1, 1, 1>(a, s)
-                 : a.Cout <= 64 ? launch_cfg<2, 2, 2, 1>(a, s) : launch_cfg<2, 2, 2, 2>(a, s);
+                 : a.Cout <= 64 ? launch_cfg<2, 2, 2, 1>(a, s)
+                 : conv_small_m((int64_t)a.B * a.H * a.W, a.Cout) ? launch_cfg<1, 4, 1, 1>(a, s) : launch_cfg<2, 2, 2, 2>(a, s);
     if (rc != OK || a.ksplit <= 1 || !with_reduce) return rc;
     return launch_splitk_reduce(a, s);
 }

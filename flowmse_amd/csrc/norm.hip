@@ -71,55 +71,60 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const ST* __restri
     }
 }
 
-// grid (G, B), 256 threads.  Channels [0,C1) take their partials from set 1 (ppb1 pixels per block), [C1,C1+C2) from
-// set 2.  Blocks and channels are merged with Chan's formula in fp64: mean and biased variance of the group.
-// (mean, 1/sqrt(var + eps)) of group g of sample b from the per-(block, channel) partials; all 256 threads of the
-// block take part and receive the result.  Two passes, both plain fp64 sums (no divisions in the loops):
-//   mean = sum n_i mean_i / N ;  var = sum (M2_i + n_i (mean_i - mean)^2) / N      (N = HW * cpg)
+// (mean, 1/sqrt(var + eps)) of group g of sample b from the per-(block, channel) partials; all 256 threads of the block
+// take part and receive the result.  Channels [0,C1) take their partials from set 1 (ppb1 pixels per block), [C1,C1+C2)
+// from set 2; a group may straddle the two sets (384 = 256 + 128: group 21).
+//
+// ONE pass over the partials, in fp64:  S1 = sum n_i mean_i,  S2 = sum (M2_i + n_i mean_i^2)  ->  mean = S1 / N,
+// var = S2 / N - mean^2 (N = HW * cpg).  The products n_i mean_i^2 of fp32 values are exact in fp64 and the
+// subtraction loses log2(mean^2 / var) of 53 bits -- at |mean| = 1e4 sigma still 1e-8 relative, far below the fp32
+// result's own rounding (the fp32 partials themselves are pivoted (mean, M2) pairs, so nothing cancels before this point).
+// Access pattern: the (mean, M2) pairs of a group's channels are CONTIGUOUS per block (nch x 8 bytes), consecutive
+// threads take consecutive pairs and then the next block -- every 128-byte line that is touched is used by nch lanes at
+// once (round 2 read one pair per lane at a stride of C x 8 bytes, twice: 64 lines per wave instruction; its launches
+// reached 680 us at [32,1,256,1024] where a sample has 2048 tile partials).
 __device__ __forceinline__ void gn_group_stats(const float* __restrict__ p1, int nblk1, int ppb1, int C1,
                                                const float* __restrict__ p2, int nblk2, int ppb2, int C2, int HW,
                                                int G, float eps, int g, int b, float& mean_out, float& rstd_out) {
-    __shared__ double wsum[4];
-    const int lane = threadIdx.x;                                       // "lane" = thread 0..255 here
+    __shared__ double wsum[8];
+    const int tid = threadIdx.x;
     const int C = C1 + C2;
     const int cpg = C / G;
-    double s1 = 0.0;
-    for (int j = 0; j < cpg; ++j) {
-        const int c = g * cpg + j;
-        const bool first = c < C1;
-        const float* p = first ? p1 : p2;
-        const int nblk = first ? nblk1 : nblk2, Cs = first ? C1 : C2, cc = first ? c : c - C1;
-        const int ppb = first ? ppb1 : ppb2;
-        for (int blk = lane; blk < nblk; blk += 256)
-            s1 += (double)min(ppb, HW - blk * ppb) * (double)p[(((int64_t)b * nblk + blk) * Cs + cc) * 2];
-    }
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o);
-    if ((lane & 63) == 0) wsum[lane >> 6] = s1;
-    __syncthreads();
-    s1 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-    const double N = (double)HW * cpg;
-    const double mu = s1 / N;
-    double s2 = 0.0;
-    for (int j = 0; j < cpg; ++j) {
-        const int c = g * cpg + j;
-        const bool first = c < C1;
-        const float* p = first ? p1 : p2;
-        const int nblk = first ? nblk1 : nblk2, Cs = first ? C1 : C2, cc = first ? c : c - C1;
-        const int ppb = first ? ppb1 : ppb2;
-        for (int blk = lane; blk < nblk; blk += 256) {
-            const float* q = p + (((int64_t)b * nblk + blk) * Cs + cc) * 2;
-            const double d = (double)q[0] - mu;
-            s2 += (double)q[1] + (double)min(ppb, HW - blk * ppb) * d * d;
+    for (int set = 0; set < 2; ++set) {
+        const float* p = set ? p2 : p1;
+        const int nblk = set ? nblk2 : nblk1, ppb = set ? ppb2 : ppb1, Cs = set ? C2 : C1;
+        const int base = set ? C1 : 0;
+        const int lo = max(c_lo, base) - base, hi = min(c_hi, base + Cs) - base;      // this set's channels of the group
+        const int nch = hi - lo;
+        if (nch <= 0 || !p) continue;
+        const float2* q = reinterpret_cast<const float2*>(p) + (int64_t)b * nblk * Cs + lo;
+        const int items = nblk * nch;
+        for (int it = tid; it < items; it += 256) {
+            const int blk = it / nch, j = it - blk * nch;
+            const float2 v = q[(int64_t)blk * Cs + j];
+            const double n = (double)min(ppb, HW - blk * ppb), m = (double)v.x;
+            s1 += n * m;
+            s2 += (double)v.y + n * m * m;
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
-    if ((lane & 63) == 0) wsum[lane >> 6] = s2;
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if ((tid & 63) == 0) {
+        wsum[tid >> 6] = s1;
+        wsum[4 + (tid >> 6)] = s2;
+    }
     __syncthreads();
-    s2 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    const double var = s2 / N;
+    s1 = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    s2 = (wsum[4] + wsum[5]) + (wsum[6] + wsum[7]);
+    const double N = (double)HW * cpg;
+    const double mu = s1 / N;
+    const double var = fmax(s2 / N - mu * mu, 0.0);
     rstd_out = (float)(1.0 / sqrt(var + (double)eps));
     mean_out = (float)mu;
 }
