@@ -238,6 +238,13 @@ struct ConvArgs {
     // statistics block (conv_splitk_stats_group) or 0 for one statistics block per 8 x 16 pixel tile (F(4,3) slices).
     unsigned* sk_ticket = nullptr;
     int sk_group = 0;
+    // Second partial set folded into the same reduction (two-pass form only): the split-K slices of ANOTHER convolution
+    // with the same output shape -- the 1x1 shortcut Conv_2(x) of a ResnetBlock, whose sum with Conv_1(h) is the block's
+    // output (layerspp.py:268-274) -- are added slice by slice after this conv's own, plus that conv's bias `bias_x`.
+    // Saves the shortcut's own reduction launch and the round trip of its output through HBM.
+    const float* partial2 = nullptr;    // [ksplit2][B*H*W][Cout]
+    int ksplit2 = 0;
+    const float* bias_x = nullptr;      // [Cout] or null
     // fused GroupNorm statistics of the OUTPUT (optional): per-(sample, pixel tile, channel) sum / sum of squares
     // written to stats[((b * stats_nblk + tile) * Cout + c) * 2 + {0,1}], the layout gn_finalize consumes.
     // Only honoured when H*W % 128 == 0 and ksplit == 1 (see conv_fused_stats_blocks).
@@ -297,6 +304,16 @@ int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps);
 // with_reduce = false: a split-K launch only writes the partial slices (the caller runs launch_splitk_reduce)
 int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce = true);
 int launch_splitk_reduce(const ConvArgs& a, hipStream_t s);
+// Reduction of a split-K conv fused with the GroupNorm that consumes its output (Conv_0 -> GroupNorm_1 of a ResnetBlock,
+// layerspp.py:262-265; the group structure G = min(Cout / 4, 32) is known when the plan is built).  One block per (group,
+// sample) sums the slices of its H*W x Cout/G elements, adds bias / per-sample bias, and -- holding the whole group --
+// computes its exact mean / variance.  apply = 1: writes act(GroupNorm(.)) to a.out (the pre-norm tensor is never
+// stored; gamma / beta / silu as given); apply = 0: writes the pre-norm tensor to a.out and the per-(sample, channel)
+// mean / scale = rstd * gamma to gn_mean / gn_scale ([B][Cout]) for a consumer that normalises on load.
+// Requires H*W * (Cout / G) <= 32768 elements per block and at least 128 blocks (conv_reduce_gn_ok).
+bool conv_reduce_gn_ok(int B, int HW, int Cout);
+int launch_splitk_reduce_gn(const ConvArgs& a, const float* gamma, const float* beta, float eps, int silu, int apply,
+                            float* gn_mean, float* gn_scale, hipStream_t s);
 // number of K slices launch_conv will use for this shape (1 = no split) and the partial-buffer size in floats
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps);
 // split-K launches reduce inside the launch (ConvArgs::sk_ticket) when FLOWSE_SPLITK_IN_LAUNCH=1 (slower, measured)

@@ -91,7 +91,21 @@ class Arena {
         live_[off] = n;
         return off;
     }
+    // Between a fork and its join the launch list runs on two streams: memory released by one branch must not be handed
+    // to the other before the join, so releases are parked and applied at the join (plan-time bookkeeping only).
+    void defer_releases(bool on) {
+        defer_ = on;
+        if (!on) {
+            std::vector<size_t> d;
+            d.swap(deferred_);
+            for (size_t off : d) release(off);
+        }
+    }
     void release(size_t off) {
+        if (defer_) {
+            deferred_.push_back(off);
+            return;
+        }
         auto it = live_.find(off);
         if (it == live_.end()) return;
         const size_t n = it->second;
@@ -114,6 +128,8 @@ class Arena {
     std::vector<std::pair<size_t, size_t>> free_;   // sorted by offset
     std::map<size_t, size_t> live_;
     size_t end_ = 0, peak_ = 0;
+    bool defer_ = false;
+    std::vector<size_t> deferred_;
 };
 
 struct Plan {
@@ -123,6 +139,10 @@ struct Plan {
     std::vector<std::string> labels;
     std::vector<double> flops, bytes;      // algorithmic work / HBM traffic of each launch
     std::vector<double> issued;            // FLOPs the matrix cores execute for it (Winograd forms: 1/2 or 2/3 of `flops`)
+    // Two-stream execution: ops flagged `side` run on the handle's side stream.  sync bit 0 (before the op): the side stream
+    // waits for everything enqueued on the main stream so far ("fork"); bit 1: the main stream waits for the side stream
+    // ("join").  Captured into the hipGraph as parallel branches; the NULL stream / profiling run everything in list order.
+    std::vector<char> side, sync;
     std::vector<char> dominant;            // 1 = a launch of the dominant kernel: the unsplit 3x3 ResBlock conv with fused
                                            // GroupNorm+SiLU input (conv3x3_f43_kernel<2, false, 2> in the fp32 mode)
     // The launch list holds no per-call argument (those live in the handle's device-resident CallBlock), so after one
@@ -174,12 +194,16 @@ struct flowse_model {
     CallBlock* d_call = nullptr;           // per-call arguments of the boundary kernels, in device memory
     unsigned* d_ticket = nullptr;          // split-K arrival counters, one per output tile (zero between launches)
     int device = -1;                       // HIP device that owns every d_* buffer of this handle
-    bool use_graph = true;                 // FLOWSE_NO_GRAPH=1: always launch eagerly
+    bool use_graph = false;                // FLOWSE_GRAPH=1: replay each shape's launch list as a hipGraph (slower, measured)
     // Callers on the NULL (legacy default) stream -- PyTorch's default stream IS the NULL stream -- cannot be captured;
     // their work runs on this internal stream instead, fenced against the NULL stream by events on both sides.
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     int64_t graph_launches = 0;            // hipGraphLaunch calls made by this handle (flowse_model_graph_launches)
+    // side branch of the launch list (Plan::side): its own stream, fork / join events from a small pool
+    hipStream_t sstream = nullptr;
+    std::vector<hipEvent_t> br_events;
+    bool use_branches = false;             // FLOWSE_BRANCH=1: the shortcut branch on a second stream (slower, measured)
     float* d_rk = nullptr;                 // fixed-step RK scratch: stage input + slope accumulator, 2 x [B,1,F,T] complex64
     size_t d_rk_floats = 0;
     // single-module handles (flowse_block_create): one ResnetBlockBigGANpp / AttnBlockpp / Combine behind the same
@@ -501,6 +525,22 @@ struct GnBuf {
     int64_t beta = -1;
 };
 
+// A split-K convolution whose reduction is left to another conv's reduction launch (ConvArgs::partial2)
+struct SkPartial {
+    size_t part_off = 0;
+    int ks = 0;
+    int64_t bias = -1;
+    bool valid = false;
+};
+// Request to fuse the GroupNorm that consumes a split-K conv's output into its reduction launch
+// (launch_splitk_reduce_gn).  apply: the conv returns act(GroupNorm(out)); else it returns out and fills `g`.
+struct GnFuse {
+    int64_t w_gamma = -1, w_beta = -1;
+    bool silu = true, apply = false;
+    GnBuf g;
+    bool done = false;
+};
+
 struct Builder {
     flowse_model* m;
     Plan* plan;
@@ -524,8 +564,30 @@ struct Builder {
         if (t.st_nblk > 0) arena.release(t.st_off);
         t.st_nblk = 0;
     }
+    // fork(): the ops recorded until side_end() form a side branch that may run concurrently with the main-stream ops
+    // recorded after it, up to join().  Usage: fork(); <side ops>; side_end(); <main ops>; join(); <consumer of both>.
+    bool failed = false;                   // an internal planning inconsistency: build_plan returns ERR_STATE
+    bool side_mode = false;
+    char pending_sync = 0;
+    bool branches = true;
+    void fork() {
+        if (!branches) return;
+        side_mode = true;
+        pending_sync |= 1;
+        arena.defer_releases(true);
+    }
+    void side_end() { side_mode = false; }
+    void join() {
+        if (!branches) return;
+        side_mode = false;
+        pending_sync |= 2;
+        arena.defer_releases(false);
+    }
     void op(const std::string& label, std::function<int(hipStream_t)> f, double flops = 0.0, double bytes = 0.0,
             bool dominant = false, double issued = -1.0) {
+        plan->side.push_back(side_mode ? 1 : 0);
+        plan->sync.push_back(pending_sync);
+        pending_sync = 0;
         plan->ops.push_back(std::move(f));
         plan->labels.push_back(label);
         plan->flops.push_back(flops);
@@ -647,10 +709,27 @@ struct Builder {
     // conv: out (new tensor unless `inplace_res`), res optional
     Tn conv(const std::string& label, const Tn& a, const Tn* b2, int64_t w, int64_t bias, int dense_row0, int Cout,
             int taps, const Tn* res, float scale, bool out_is_res = false, bool cin4 = false,
-            const GnBuf* gin = nullptr, bool gin_silu = false, int64_t wq_off = -1, int out_dt = -1) {
+            const GnBuf* gin = nullptr, bool gin_silu = false, int64_t wq_off = -1, int out_dt = -1,
+            SkPartial* defer = nullptr, const SkPartial* extra = nullptr, GnFuse* gnf = nullptr) {
         flowse_model* M = m;
-        Tn o = out_is_res ? *res : alloc(a.H, a.W, Cout, out_dt);
         const int C1 = a.C, C2 = b2 ? b2->C : 0, H = a.H, Wd = a.W, Bn = B;
+        {   // a deferred reduction leaves no output tensor: decide before anything is allocated
+            const bool in16_ = a.dt != DT_F32;
+            const int ks_ = cin4 ? 1 : in16_ ? ((conv_supports_head4(Bn, H, Wd, C1, C2, Cout, taps) || conv16_uses_halo(Bn, H, Wd, C1, C2, Cout, taps))
+                                                    ? 1 : conv16_ksplit(Bn, H, Wd, C1 + C2, Cout, taps))
+                                             : conv_ksplit(Bn, H, Wd, C1 + C2, Cout, taps);
+            if (defer && !(ks_ > 1 && !conv_splitk_in_launch() && !res && dense_row0 < 0)) defer = nullptr;
+            if ((extra || gnf) && !(ks_ > 1 && !conv_splitk_in_launch())) {
+                if (extra && extra->valid) {
+                    set_error("internal: merged reduction requested for an unsplit conv (%s)", label.c_str());
+                    failed = true;
+                }
+                gnf = nullptr;
+            }
+            if (gnf && (res || !conv_reduce_gn_ok(Bn, H * Wd, Cout))) gnf = nullptr;
+        }
+        Tn o;
+        if (!defer) o = out_is_res ? *res : alloc(a.H, a.W, Cout, out_dt);
         const size_t a_off = a.off, b_off = b2 ? b2->off : 0, o_off = o.off, r_off = res ? res->off : 0;
         const bool has2 = b2 != nullptr, hasres = res != nullptr;
         const int idt = a.dt, odt = o.dt;
@@ -663,6 +742,7 @@ struct Builder {
                                                                                  : conv16_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps))
                              : conv_fused_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps);
         if (cin4 && !out_is_res && C1 == 4 && !has2 && conv_cin4_uses_mfma(Bn, H, Wd, Cout, taps)) st_nblk = H * Wd / 128;
+        if (defer || gnf) st_nblk = 0;                   // no output here / the statistics are finished inside the reduction
         if (st_nblk > 0) {
             o.st_nblk = st_nblk;
             o.st_off = arena.alloc((size_t)Bn * st_nblk * Cout * 2 * sizeof(float));
@@ -682,6 +762,8 @@ struct Builder {
         const bool sk_in_launch = ks > 1 && conv_splitk_in_launch() && sk_tiles <= SK_TICKETS;
         const int sk_group = st_nblk > 0 ? H * Wd / st_nblk : 0;
         const size_t table_off = M_table_off;     // by value: the Builder dies before the plan runs
+        const bool has_extra = extra != nullptr && extra->valid;
+        const SkPartial xp = has_extra ? *extra : SkPartial();
         const std::string full_label = label + "@" + std::to_string(H) + "x" + std::to_string(Wd) + ":" +
                                        std::to_string(C1 + C2) + ">" + std::to_string(Cout);
         auto make_args = [=]() {
@@ -701,6 +783,11 @@ struct Builder {
             c.scale = scale;
             c.ksplit = ks;
             c.partial = ks > 1 ? M->A(part_off) : nullptr;
+            if (has_extra) {
+                c.partial2 = M->A(xp.part_off);
+                c.ksplit2 = xp.ks;
+                c.bias_x = xp.bias >= 0 ? M->W(xp.bias) : nullptr;
+            }
             if (sk_in_launch) {
                 c.sk_ticket = M->d_ticket;
                 c.sk_group = sk_group;
@@ -739,9 +826,32 @@ struct Builder {
            has_gin && Cout > 64 && ks == 1 &&
                (wino_off < 0 || !conv_wino_default_f43() || conv_f43_forced_bn64() || conv_f43_wide(Bn, H, Wd, Cout)),
            wino_off >= 0 ? flops * (conv_wino_default_f43() ? 0.5 : 2.0 / 3.0) : (use_bf16 && terms == 3) ? 3.0 * flops : flops);
-        if (ks > 1 && !sk_in_launch)
+        if (defer) {                                     // the consumer's reduction sums these slices (ConvArgs::partial2)
+            defer->part_off = part_off;
+            defer->ks = ks;
+            defer->bias = bias;
+            defer->valid = true;
+            return Tn();
+        }
+        if (ks > 1 && !sk_in_launch && gnf) {
+            const int64_t wg = gnf->w_gamma, wb = gnf->w_beta;
+            const bool gsilu = gnf->silu, gapply = gnf->apply;
+            GnBuf g;
+            if (!gapply) {
+                g.mean = arena.alloc((size_t)Bn * Cout * sizeof(float));
+                g.scale = arena.alloc((size_t)Bn * Cout * sizeof(float));
+                g.beta = wb;
+            }
+            const size_t gm = g.mean, gs = g.scale;
+            op("splitk_reduce_gn@" + std::to_string(H) + "x" + std::to_string(Wd), [=](hipStream_t s) {
+                return launch_splitk_reduce_gn(make_args(), M->W(wg), M->W(wb), 1e-6f, gsilu ? 1 : 0, gapply ? 1 : 0,
+                                               gapply ? nullptr : M->A(gm), gapply ? nullptr : M->A(gs), s);
+            }, 8.0 * Bn * H * Wd * Cout, part_bytes + out_bytes);
+            gnf->g = g;
+            gnf->done = true;
+        } else if (ks > 1 && !sk_in_launch)
             op("splitk_reduce@" + std::to_string(H) + "x" + std::to_string(Wd), [=](hipStream_t s) { return launch_splitk_reduce(make_args(), s); }, 0.0,
-               part_bytes + out_bytes);
+               part_bytes * (has_extra ? 1.0 + (double)xp.ks / ks : 1.0) + out_bytes);
         if (ks > 1) arena.release(part_off);
         return o;
     }
@@ -776,49 +886,95 @@ struct Builder {
     Tn resblock(const Module& mod, const Tn& x1, const Tn* x2) {
         const float rs2 = 0.70710678118654752440f;
         Tn h1, xs;
-        auto fusable = [&](const Tn& t, int c2) {       // Conv(act(GroupNorm(t))) as one kernel for this shape?
-            return t.dt != DT_F32 ? conv16_uses_halo(B, t.H, t.W, t.C, c2, mod.out_ch, 9)
-                                  : conv_supports_fused_gn(B, t.H, t.W, t.C, c2, mod.out_ch, 9);
+        auto fusable_shape = [&](int dt, int H, int W, int C, int c2) {   // Conv(act(GroupNorm(t))) as one kernel for this shape?
+            return dt != DT_F32 ? conv16_uses_halo(B, H, W, C, c2, mod.out_ch, 9)
+                                : conv_supports_fused_gn(B, H, W, C, c2, mod.out_ch, 9);
         };
+        auto fusable = [&](const Tn& t, int c2) { return fusable_shape(t.dt, t.H, t.W, t.C, c2); };
+        // output geometry of the block (Conv_0 already runs at the resampled size)
+        const int Ho = mod.up ? 2 * x1.H : mod.down ? x1.H / 2 : x1.H, Wo = mod.up ? 2 * x1.W : mod.down ? x1.W / 2 : x1.W;
+        // Small images run split over K with a separate reduction launch.  Two of those launches disappear here:
+        //  * Conv_0's reduction also finishes GroupNorm_1 (its group structure is known): it returns act(GN_1(.)) where
+        //    the next conv wants a materialised input, or the pre-norm tensor plus per-channel mean / scale where the
+        //    next conv normalises on load (GnFuse);
+        //  * the shortcut Conv_2(x) leaves its slices to Conv_1's reduction, which sums both sets (SkPartial).
+        GnFuse gf;
+        gf.w_gamma = mod.w_gn1_g;
+        gf.w_beta = mod.w_gn1_b;
+        gf.silu = true;
+        gf.apply = !fusable_shape(m->act_dt, Ho, Wo, mod.out_ch, 0);
+        SkPartial sp;
+        const bool merge_sc = mod.shortcut && sk_two_pass(x1.dt, Ho, Wo, mod.out_ch, mod.out_ch, 9) &&
+                              sk_two_pass(x1.dt, Ho, Wo, mod.in_ch, mod.out_ch, 1);
         if (!mod.up && !mod.down) {
+            if (mod.shortcut) {      // Conv_2(x) is independent of GN_0 -> Conv_0 -> GN_1: a side branch up to Conv_1's launch
+                fork();
+                xs = conv("conv2_1x1", x1, x2, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f, false, false, nullptr,
+                          false, -1, -1, merge_sc ? &sp : nullptr);
+                side_end();
+            }
             if (fusable(x1, x2 ? x2->C : 0)) {
                 // Conv_0(act(GroupNorm_0(x))) in one kernel: the normalised tensor never reaches HBM
                 GnBuf g0 = gn(x1, x2, mod.w_gn0_g, mod.w_gn0_b);
                 h1 = conv("conv0_3x3_gn", x1, x2, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f, false,
-                          false, &g0, true, mod.wq_c0);
+                          false, &g0, true, mod.wq_c0, -1, nullptr, nullptr, &gf);
                 gn_release(g0);
             } else {
                 Tn h0 = gn_norm(x1, x2, mod.w_gn0_g, mod.w_gn0_b, true);
-                h1 = conv("conv0_3x3", h0, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f);
+                h1 = conv("conv0_3x3", h0, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f, false, false,
+                          nullptr, false, -1, -1, nullptr, nullptr, &gf);
                 release(h0);
             }
-            if (mod.shortcut) xs = conv("conv2_1x1", x1, x2, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f);
         } else {
             GnBuf g0 = gn(x1, x2, mod.w_gn0_g, mod.w_gn0_b);
             Tn xr;
             Tn hr = fir(x1, mod.up, &g0, true, nullptr, false, &xr);      // act(GN(x)) and x resampled in one pass
             gn_release(g0);
+            // the shortcut Conv_2(x) (layerspp.py:268-270) does not depend on the GN -> Conv_0 -> GN chain: side branch
+            fork();
+            xs = conv("conv2_1x1", xr, nullptr, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f, false, false, nullptr,
+                      false, -1, -1, merge_sc ? &sp : nullptr);
+            side_end();
             h1 = conv("conv0_3x3", hr, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f, false, false,
-                      nullptr, false, mod.wq_c0);
+                      nullptr, false, mod.wq_c0, -1, nullptr, nullptr, &gf);
             release(hr);
-            xs = conv("conv2_1x1", xr, nullptr, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f);
             release(xr);
         }
         Tn out;
-        if (fusable(h1, 0)) {
-            GnBuf g1 = gn(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b);
-            out = conv("conv1_3x3_gn", h1, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, xs.valid() ? &xs : &x1, rs2,
-                       false, false, &g1, true, mod.wq_c1);
+        const bool forked = mod.shortcut;
+        const Tn* resid = sp.valid ? nullptr : (xs.valid() ? &xs : &x1);
+        const SkPartial* extra = sp.valid ? &sp : nullptr;
+        if (gf.done && gf.apply) {                       // h1 already is act(GroupNorm_1(Conv_0(.)))
+            if (forked) join();
+            out = conv("conv1_3x3", h1, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, resid, rs2, false, false, nullptr,
+                       false, -1, -1, nullptr, extra);
+            release(h1);
+        } else if (fusable(h1, 0)) {
+            GnBuf g1 = gf.done ? gf.g : gn(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b);
+            if (forked) join();
+            out = conv("conv1_3x3_gn", h1, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, resid, rs2,
+                       false, false, &g1, true, mod.wq_c1, -1, nullptr, extra);
             gn_release(g1);
             release(h1);
         } else {
             Tn h2 = gn_norm(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b, true);
             release(h1);
-            out = conv("conv1_3x3", h2, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, xs.valid() ? &xs : &x1, rs2);
+            if (forked) join();
+            out = conv("conv1_3x3", h2, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, resid, rs2, false, false, nullptr,
+                       false, -1, -1, nullptr, extra);
             release(h2);
         }
+        if (sp.valid) arena.release(sp.part_off);
         release(xs);
         return out;
+    }
+    // true when a conv of this shape runs split over K with the separate (two-pass) reduction launch
+    bool sk_two_pass(int dt, int H, int W, int Cin, int Cout, int taps) const {
+        if (conv_splitk_in_launch() || getenv("FLOWSE_NO_MERGED_REDUCE")) return false;
+        const int ks = dt != DT_F32 ? ((conv_supports_head4(B, H, W, Cin, 0, Cout, taps) || conv16_uses_halo(B, H, W, Cin, 0, Cout, taps))
+                                           ? 1 : conv16_ksplit(B, H, W, Cin, Cout, taps))
+                                    : conv_ksplit(B, H, W, Cin, Cout, taps);
+        return ks > 1;
     }
 
     // AttnBlockpp.forward, layerspp.py:75-91
@@ -861,6 +1017,7 @@ static int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
     bd.m = m;
     bd.plan = plan;
     bd.B = B;
+    bd.branches = m->use_branches;
     flowse_model* M = m;
     const int nf = c.nf, td = m->temb_dim;
     size_t mi = 0;
@@ -985,7 +1142,7 @@ static int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
         });
     }
     plan->ws_bytes = bd.arena.peak();
-    return OK;
+    return bd.failed ? ERR_STATE : OK;
 }
 
 static void drop_graph(Plan* p) {
@@ -1061,7 +1218,37 @@ static int run_plan(flowse_model* m, Plan* p, hipStream_t s) {
         }
         m->prof_tot_launches += (int64_t)p->ops.size();
     }
+    // two-stream execution of the side branches (never while profiling -- per-launch events want one stream -- and never
+    // on the NULL stream, which serialises against every blocking stream anyway)
+    const bool multi = m->use_branches && m->prof_mode == -1 && s != nullptr;
+    size_t ev_used = 0;
+    auto next_event = [&](hipEvent_t* e) -> int {
+        if (ev_used == m->br_events.size()) {
+            hipEvent_t ev;
+            FLOWSE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            m->br_events.push_back(ev);
+        }
+        *e = m->br_events[ev_used++];
+        return OK;
+    };
+    if (multi && !m->sstream) FLOWSE_HIP(hipStreamCreateWithFlags(&m->sstream, hipStreamNonBlocking));
+    bool side_open = false;                 // the side stream holds work the main stream has not joined yet
     for (size_t i = 0; i < p->ops.size(); ++i) {
+        if (multi && p->sync[i]) {
+            hipEvent_t ev;
+            if (p->sync[i] & 2) {           // join: main waits for the side branch
+                if (const int rc = next_event(&ev)) return rc;
+                FLOWSE_HIP(hipEventRecord(ev, m->sstream));
+                FLOWSE_HIP(hipStreamWaitEvent(s, ev, 0));
+                side_open = false;
+            }
+            if (p->sync[i] & 1) {           // fork: the side branch starts after everything enqueued on main so far
+                if (const int rc = next_event(&ev)) return rc;
+                FLOWSE_HIP(hipEventRecord(ev, s));
+                FLOWSE_HIP(hipStreamWaitEvent(m->sstream, ev, 0));
+                side_open = true;
+            }
+        }
         const bool prof = m->prof_mode == 1 || (m->prof_mode == 0 && p->dominant[i]);
         flowse_model::Pending pd;
         if (prof) {
@@ -1098,12 +1285,18 @@ static int run_plan(flowse_model* m, Plan* p, hipStream_t s) {
             if (drop) continue;
         }
 #endif
-        const int rc = p->ops[i](s);
+        const int rc = p->ops[i]((multi && p->side[i]) ? m->sstream : s);
         if (rc != OK) return rc;
         if (prof) {
             FLOWSE_HIP(hipEventRecord(pd.b, s));
             m->prof_pending.push_back(pd);
         }
+    }
+    if (multi && side_open) {               // (every fork is joined by construction; belt and braces for stream capture)
+        hipEvent_t ev;
+        if (const int rc = next_event(&ev)) return rc;
+        FLOWSE_HIP(hipEventRecord(ev, m->sstream));
+        FLOWSE_HIP(hipStreamWaitEvent(s, ev, 0));
     }
     return OK;
 }
@@ -1159,7 +1352,7 @@ static int exec_plan(flowse_model* m, Plan* p, hipStream_t s) {
 // for everything the caller has enqueued on the NULL stream; leave_stream() makes the NULL stream wait for the call.
 static int enter_stream(flowse_model* m, hipStream_t caller, hipStream_t* work) {
     *work = caller;
-    if (caller != nullptr || !m->use_graph || m->prof_mode != -1) return OK;
+    if (caller != nullptr || !(m->use_graph || m->use_branches) || m->prof_mode != -1) return OK;
     if (!m->gstream) {
         FLOWSE_HIP(hipStreamCreateWithFlags(&m->gstream, hipStreamNonBlocking));
         FLOWSE_HIP(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
@@ -1194,6 +1387,7 @@ static int build_block_plan(flowse_model* m, Plan* plan, int B, int H, int W, in
     bd.m = m;
     bd.plan = plan;
     bd.B = B;
+    bd.branches = m->use_branches;
     flowse_model* M = m;
     const int td = m->temb_dim;
     Tn x1 = bd.alloc(H, W, C1), x2;
@@ -1230,7 +1424,7 @@ static int build_block_plan(flowse_model* m, Plan* plan, int B, int H, int W, in
         bd.op("block_out", [=](hipStream_t s) { return launch_convert(M->A(o), od, M->bcall.out, DT_F32, n, s); });
     }
     plan->ws_bytes = bd.arena.peak();
-    return OK;
+    return bd.failed ? ERR_STATE : OK;
 }
 
 static void free_device_state(flowse_model* m) {
@@ -1251,6 +1445,10 @@ static void free_device_state(flowse_model* m) {
     if (m->d_rk) (void)hipFree(m->d_rk);
     m->d_rk = nullptr;
     m->d_rk_floats = 0;
+    if (m->sstream) (void)hipStreamDestroy(m->sstream);
+    m->sstream = nullptr;
+    for (hipEvent_t e : m->br_events) (void)hipEventDestroy(e);
+    m->br_events.clear();
     if (m->gstream) (void)hipStreamDestroy(m->gstream);
     if (m->ev_in) (void)hipEventDestroy(m->ev_in);
     if (m->ev_out) (void)hipEventDestroy(m->ev_out);
@@ -1292,7 +1490,14 @@ int flowse_model_create(const flowse_config* cfg, flowse_model** out) {
     }
     flowse_model* m = new flowse_model();
     m->cfg = *cfg;
-    m->use_graph = getenv("FLOWSE_NO_GRAPH") == nullptr;
+    // hipGraph replay of the launch list is opt-in (FLOWSE_GRAPH=1): measured on MI355X / ROCm 7.2 a replayed graph of
+    // ~400 short kernel nodes runs 5 % SLOWER than the same launches issued eagerly from the C loop at [1,1,256,256]
+    // (8.09 k vs 8.55 k frames/s) and equal at [8,1,256,256]; the host is nowhere near launch-bound (~1.5 ms of launch
+    // calls per 6 ms network evaluation at batch 1).  FLOWSE_NO_GRAPH=1 is accepted for compatibility.
+    m->use_graph = getenv("FLOWSE_GRAPH") != nullptr && getenv("FLOWSE_NO_GRAPH") == nullptr;
+    // Two-stream execution of the shortcut branch is opt-in as well (FLOWSE_BRANCH=1): the fork / join events cost more
+    // than the overlap returns -- 17.05 k vs 17.5 k frames/s at [8,1,256,256], 8.2 k vs 8.65 k at [1,1,256,256].
+    m->use_branches = getenv("FLOWSE_BRANCH") != nullptr;
     const int rc = build_structure(m);
     if (rc != OK) {
         delete m;
@@ -1319,6 +1524,7 @@ int flowse_block_create(int kind, int in_ch, int out_ch, int up, int down, int t
     flowse_model* m = new flowse_model();
     memset(&m->cfg, 0, sizeof(m->cfg));
     m->use_graph = false;
+    m->use_branches = getenv("FLOWSE_BRANCH") != nullptr;
     m->block_kind = kind;
     m->temb_dim = temb_dim;
     if (kind == FLOWSE_BLOCK_RESNET) add_module(m, resblock(in_ch, out_ch, up != 0, down != 0));

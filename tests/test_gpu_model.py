@@ -16,9 +16,23 @@ TOL = 1e-3          # north_star bar
 TIGHT = 1e-4        # what the fp32 MFMA path is expected to reach
 
 
-def _model(cfg, tag=None):
+def _model(cfg, tag=None, graph=False):
+    """graph=True: a handle that replays its launch list as a hipGraph (opt-in, FLOWSE_GRAPH=1 is read when the handle is
+    created; the default is eager launches, which measure faster on MI355X)."""
+    import os
     from flowmse_amd.model import VFModel
-    m = VFModel(backbone="ncsnpp", ode="flowmatching", **cfg)
+    old = os.environ.get("FLOWSE_GRAPH")
+    if graph:
+        os.environ["FLOWSE_GRAPH"] = "1"
+    else:
+        os.environ.pop("FLOWSE_GRAPH", None)
+    try:
+        m = VFModel(backbone="ncsnpp", ode="flowmatching", **cfg)
+    finally:
+        if old is None:
+            os.environ.pop("FLOWSE_GRAPH", None)
+        else:
+            os.environ["FLOWSE_GRAPH"] = old
     names = [n for n, _ in m.dnn.named_parameters()]
     sd = {n: torch.from_numpy(synth.synth_param(n, tuple(p.shape))) for n, p in m.dnn.named_parameters()}
     m.dnn.load_state_dict(sd)
@@ -78,12 +92,13 @@ def test_generic_solver_loop_matches_fused(tiny):
 
 
 @pytest.mark.parametrize("solver,N", [("heun", 3), ("rk4", 2)])
-def test_fixed_step_rk_against_oracle_composition(tiny, solver, N):
+def test_fixed_step_rk_against_oracle_composition(solver, N):
     """Fixed-step RK (BASELINE config 5's solver) has no reference counterpart: pinned by composing the oracle VF in
     the same tableau (oracle/sampler_oracle.py:rk_sample), final step = Euler (never evaluates below t_eps)."""
     from flowmse_amd.sampling import get_white_box_solver
     from oracle import ncsnpp_oracle as O
     from oracle import sampler_oracle as S
+    tiny = _model(C.TINY, graph=True)            # graph replay on: the launch counter shows that the fused entry ran
     t = C.param_tables()["tiny"]
     w = C.synth_weights(t["names"], t["shapes"])
     cfg = O.make_cfg(**C.TINY)
@@ -423,10 +438,13 @@ def test_enhance_sharded_ragged_matches_per_utterance(tiny):
         assert padded[i].shape == ref.shape and C.rel_l2(padded[i], ref.cpu()) < 1e-5
 
 
-def test_graph_replay_equals_eager_launches(tiny):
-    """A shape's launch list is captured as a hipGraph on its second use: replays must be bit-identical to the eager
-    passes (same kernels, same order), for the vector field and for the fused sampler with changing t / dt."""
+def test_graph_replay_equals_eager_launches():
+    """FLOWSE_GRAPH=1: a shape's launch list is captured as a hipGraph on its second use: replays must be bit-identical to
+    the eager passes (same kernels, same order), for the vector field and for the fused sampler with changing t / dt --
+    and bit-identical to a default (eager, two-stream) handle."""
     from flowmse_amd.sampling import get_white_box_solver
+    tiny = _model(C.TINY, graph=True)
+    eager_model = _model(C.TINY)
     xt, y, z = C.tiny_inputs()
     X, Y, Z = xt.cuda(), y.cuda(), z.cuda()
     outs = [tiny(X, torch.tensor([0.03, 1.0], device="cuda"), Y).clone() for _ in range(4)]   # eager, capture, replay x2
@@ -438,6 +456,9 @@ def test_graph_replay_equals_eager_launches(tiny):
     g = C.gold("tiny_sampler")
     got = get_white_box_solver("euler", tiny.ode, tiny, Y=Y, N=5, z=Z)()[0]
     assert C.rel_l2(got.cpu(), g["x_N5"]) < TIGHT
+    assert tiny.dnn.graph_launches() > 0 and eager_model.dnn.graph_launches() == 0
+    want = get_white_box_solver("euler", eager_model.ode, eager_model, Y=Y, N=5, z=Z)()[0]
+    assert torch.equal(got, want), "graph replay and eager two-stream launches differ"
 
 
 def test_graphs_really_replay_on_the_default_and_on_side_streams():
@@ -446,7 +467,7 @@ def test_graphs_really_replay_on_the_default_and_on_side_streams():
     compared eager launches with eager launches), on the default stream and on a caller-owned side stream, and results
     of eager pass / capture pass / replays are bit-identical and correctly ordered against surrounding torch work."""
     from flowmse_amd.sampling import get_white_box_solver
-    m = _model(C.TINY)                          # fresh handle: counter starts at 0
+    m = _model(C.TINY, graph=True)              # fresh handle with graph replay on: counter starts at 0
     xt, y, z = C.tiny_inputs()
     X, Y, Z = xt.cuda(), y.cuda(), z.cuda()
     t = torch.tensor([0.03, 1.0], device="cuda")
