@@ -242,6 +242,10 @@ struct ConvArgs {
     // with the same output shape -- the 1x1 shortcut Conv_2(x) of a ResnetBlock, whose sum with Conv_1(h) is the block's
     // output (layerspp.py:268-274) -- are added slice by slice after this conv's own, plus that conv's bias `bias_x`.
     // Saves the shortcut's own reduction launch and the round trip of its output through HBM.
+    // F(4,3) kernel: walk the pixel tiles last-to-first (FLOWSE_F43_SNAKE=1 alternates the direction from one launch to
+    // the next so that a conv starts with the part of its input its predecessor wrote last; measured: no effect -- the
+    // 268 MB activations of the 256 x 256 level do not survive in the 256 MB Infinity Cache either way).  A-B hook.
+    int reverse = 0;
     const float* partial2 = nullptr;    // [ksplit2][B*H*W][Cout]
     int ksplit2 = 0;
     const float* bias_x = nullptr;      // [Cout] or null

@@ -2105,7 +2105,9 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
     const int n_ntiles = a.Cout / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     // a block owns `tpb` consecutive pixel tiles (in walk order) of ONE channel block
-    const int mg = bid / n_ntiles, nt = bid - mg * n_ntiles;
+    int mg = bid / n_ntiles;
+    const int nt = bid - mg * n_ntiles;
+    if (a.reverse) mg = (int)gridDim.x / n_ntiles - 1 - mg;
     const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 3);
     const int n0 = nt * BN;
     const int col4 = tid & 7, row0 = tid >> 3;
@@ -2186,8 +2188,13 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
         }
     };
     auto gloadH = [&](const F43Tile& t, int chunk, int h) {
+#ifdef FLOWSE_PROBE_NOHALO      /* measurement probe: no halo loads inside the loop (results are garbage, timing what-if) */
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rh[q] = u32x4{(unsigned)chunk, (unsigned)h, (unsigned)q, 0x3f800000u};
+#else
 #pragma unroll
         for (int q = 0; q < 3; ++q) rh[q] = hload(t, chunk, 3 * h + q);
+#endif
         if (h == 0) {
             gparams(t, chunk);
             st_hin = t.hin;
@@ -2323,8 +2330,18 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
         acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[(c == 0 && CH == 1) ? 4 : c].K, BF[c][j].K, acc[c][j], 0, 0, 0);
     // One k-block: request the next block's operands (halo rows from LDS, weights from L2), run this block's 12
     // MFMAs with the next block's transform (and one staged halo quad) fenced in between
-#define FLOWSE_WPHASE(V, BF, NKX, NJ, NCHK, DN, BFN, XQ)                                                             \
-    FLOWSE_WLOADA(NKX, NJ, DN) FLOWSE_WLOADB(NKX, NJ, NCHK, BFN) FLOWSE_FENCE                                        \
+    // HL >= 0: this phase also requests half HL of the next chunk's halo -- AFTER its own operand requests.  Vector
+    // memory loads return (and vmcnt counts) in issue order, so every weight fragment requested after a halo load waits
+    // for that load's HBM round trip.  Without the in-loop halo loads (probe build, results garbage) the kernel is 6-8 %
+    // faster and the difference is exactly the waves' parked time (SQ_WAIT_ANY 1.19e8 -> 0.74e8 quad-cycles per launch,
+    // profiles/r03_f43_probes.md).  Requesting the halo behind the phase's weights and normalising it three phases later
+    // instead of one (this schedule) did NOT recover it (447 vs 447 us): the wait is not a fixed latency one can cover
+    // with 3 000 cycles but the tail of the HBM round trips of the 8 load batches a block issues per chunk, which gates
+    // the chunk barrier.  FLOWSE_F43_HALO_EARLY selects round 2's schedule (A-B builds).
+#define FLOWSE_WPHASE(V, BF, NKX, NJ, NCHK, DN, BFN, XQ, HL)                                                         \
+    FLOWSE_WLOADA(NKX, NJ, DN) FLOWSE_WLOADB(NKX, NJ, NCHK, BFN)                                                     \
+    if ((HL) >= 0) gloadH(stile, cnext, (HL) < 0 ? 0 : (HL));                                                        \
+    FLOWSE_FENCE                                                                                                     \
     FLOWSE_WMMA3(V, BF, x) FLOWSE_FENCE                                                                              \
     if (GN && (XQ) >= 0) xform1((XQ) < 0 ? 0 : (XQ));                                                                \
     FLOWSE_FENCE FLOWSE_WMMA3(V, BF, y) FLOWSE_FENCE                                                                 \
@@ -2358,29 +2375,54 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
         const bool wrap = chunk + 1 >= c_end;            // the tile's last chunk stages for the block's next tile
         const int cnext = wrap ? (more ? c_begin : c_end - 1) : chunk + 1, nbuf = (chunk - c_begin + 1) & 1;
         const F43Tile& stile = (wrap && more) ? nxt : cur;
-        gloadH(stile, cnext, 0);                         // next chunk's halo, first half
         FLOWSE_WLOADA(0, 0, dA)
         FLOWSE_WXA(dA) FLOWSE_WXB(dA)
         FLOWSE_FENCE
-        FLOWSE_WPHASE(dA, bA, 0, 1, chunk, dB, bB, -1)
-        FLOWSE_WPHASE(dB, bB, 0, 2, chunk, dA, bA, 0)
-        FLOWSE_WPHASE(dA, bA, 0, 3, chunk, dB, bB, 1)
-        FLOWSE_WPHASE(dB, bB, 1, 0, chunk, dA, bA, 2)
-        lstoreH(nbuf, 0);                                // the idle buffer: nobody reads it during this chunk
-        gloadH(stile, cnext, 1);                         // second half
+#ifdef FLOWSE_F43_HALO_EARLY   /* round-2 schedule (A-B builds): halo requested right before the next phase's weights, normalised from the next phase on */
+        gloadH(stile, cnext, 0);
+        FLOWSE_WPHASE(dA, bA, 0, 1, chunk, dB, bB, -1, -1)
+        FLOWSE_WPHASE(dB, bB, 0, 2, chunk, dA, bA, 0, -1)
+        FLOWSE_WPHASE(dA, bA, 0, 3, chunk, dB, bB, 1, -1)
+        FLOWSE_WPHASE(dB, bB, 1, 0, chunk, dA, bA, 2, -1)
+        lstoreH(nbuf, 0);
+        gloadH(stile, cnext, 1);
         FLOWSE_FENCE
-        FLOWSE_WPHASE(dA, bA, 1, 1, chunk, dB, bB, -1)
-        FLOWSE_WPHASE(dB, bB, 1, 2, chunk, dA, bA, 3)
-        FLOWSE_WPHASE(dA, bA, 1, 3, chunk, dB, bB, 4)
-        FLOWSE_WPHASE(dB, bB, 2, 0, chunk, dA, bA, 5)
+        FLOWSE_WPHASE(dA, bA, 1, 1, chunk, dB, bB, -1, -1)
+        FLOWSE_WPHASE(dB, bB, 1, 2, chunk, dA, bA, 3, -1)
+        FLOWSE_WPHASE(dA, bA, 1, 3, chunk, dB, bB, 4, -1)
+        FLOWSE_WPHASE(dB, bB, 2, 0, chunk, dA, bA, 5, -1)
         lstoreH(nbuf, 1);
         FLOWSE_FENCE
-        FLOWSE_WPHASE(dA, bA, 2, 1, chunk, dB, bB, -1)
-        FLOWSE_WPHASE(dB, bB, 2, 2, chunk, dA, bA, -1)
-        FLOWSE_WPHASE(dA, bA, 2, 3, chunk, dB, bB, -1)
+        FLOWSE_WPHASE(dA, bA, 2, 1, chunk, dB, bB, -1, -1)
+        FLOWSE_WPHASE(dB, bB, 2, 2, chunk, dA, bA, -1, -1)
+        FLOWSE_WPHASE(dA, bA, 2, 3, chunk, dB, bB, -1, -1)
         FLOWSE_WLOADB(0, 0, cnext, bA) FLOWSE_FENCE       // first weights of the next chunk
         FLOWSE_WMMA3(dB, bB, x) FLOWSE_WMMA3(dB, bB, y) FLOWSE_WMMA3(dB, bB, z) FLOWSE_WMMA3(dB, bB, w)
         FLOWSE_FENCE
+#else
+        // twelve phases; the next chunk's halo: first half requested in phase 1, normalised in phases 4-6, second half
+        // requested in phase 7, normalised in phases 10-12 (the idle buffer: nobody reads it during this chunk)
+        FLOWSE_WPHASE(dA, bA, 0, 1, chunk, dB, bB, -1, 0)
+        FLOWSE_WPHASE(dB, bB, 0, 2, chunk, dA, bA, -1, -1)
+        FLOWSE_WPHASE(dA, bA, 0, 3, chunk, dB, bB, -1, -1)
+        FLOWSE_WPHASE(dB, bB, 1, 0, chunk, dA, bA, 0, -1)
+        FLOWSE_WPHASE(dA, bA, 1, 1, chunk, dB, bB, 1, -1)
+        FLOWSE_WPHASE(dB, bB, 1, 2, chunk, dA, bA, 2, -1)
+        lstoreH(nbuf, 0);
+        FLOWSE_FENCE
+        FLOWSE_WPHASE(dA, bA, 1, 3, chunk, dB, bB, -1, 1)
+        FLOWSE_WPHASE(dB, bB, 2, 0, chunk, dA, bA, -1, -1)
+        FLOWSE_WPHASE(dA, bA, 2, 1, chunk, dB, bB, -1, -1)
+        FLOWSE_WPHASE(dB, bB, 2, 2, chunk, dA, bA, 3, -1)
+        FLOWSE_WPHASE(dA, bA, 2, 3, chunk, dB, bB, 4, -1)
+        FLOWSE_WLOADB(0, 0, cnext, bA) FLOWSE_FENCE       // first weights of the next chunk
+        FLOWSE_WMMA3(dB, bB, x) FLOWSE_FENCE
+        if (GN) xform1(5);
+        FLOWSE_FENCE
+        FLOWSE_WMMA3(dB, bB, y) FLOWSE_WMMA3(dB, bB, z) FLOWSE_WMMA3(dB, bB, w)
+        FLOWSE_FENCE
+        lstoreH(nbuf, 1);
+#endif
         __syncthreads();     // next chunk's halo is complete; everyone has left this chunk's
     }
 #undef FLOWSE_WLOADA
@@ -2581,10 +2623,15 @@ static int launch_f43(const ConvArgs& a, hipStream_t s) {
 #endif
     const size_t lds = wide && lds_c > lds_halo ? lds_c : lds_halo;
     const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;
+    static const int snake = getenv("FLOWSE_F43_SNAKE") ? atoi(getenv("FLOWSE_F43_SNAKE")) : 0;   // A-B hook, see ConvArgs::reverse
+    static int flip = 0;                                 // (launch order is the plan's order: deterministic per process)
+    ConvArgs ar = a;
+    if (snake == 1 && !a.partial) ar.reverse = (flip++) & 1;
+    else if (snake == 2 && !a.partial) ar.reverse = 1;
 #define FLOWSE_LF43(G, SP, TNV)                                                                              \
     {                                                                                                        \
         if (const int rc = allow_lds<&conv3x3_f43_kernel<G, SP, TNV>>(lds)) return rc;                       \
-        hipLaunchKernelGGL((conv3x3_f43_kernel<G, SP, TNV>), dim3(grid, ks), dim3(256), lds, s, a, tpb);          \
+        hipLaunchKernelGGL((conv3x3_f43_kernel<G, SP, TNV>), dim3(grid, ks), dim3(256), lds, s, ar, tpb);         \
     }
     if (a.partial) {
         if (gn == 2) FLOWSE_LF43(2, true, 1) else if (gn == 1) FLOWSE_LF43(1, true, 1) else FLOWSE_LF43(0, true, 1)
