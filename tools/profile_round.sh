@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for one round (run on the GPU box via gpurun; outputs under gpurun_out/prof_*; summarise with
 # tools/summarize_profiles.py <tag>).  Counters in their own passes, only --kernel-trace beside them.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt"
