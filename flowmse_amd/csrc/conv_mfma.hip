@@ -1932,7 +1932,12 @@ constexpr int F43_HROW = 18 * LDS_ROW + 8;
 template <int CH>
 __device__ __forceinline__ void f43_out_exchange(const ConvArgs& a, f32x16 (&acc)[3][2], float* smem, int b, int y0, int x0,
                                                  int n0, int tile) {
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    // Opaque to the optimiser: everything below that depends only on the lane (row-pass offsets, LDS addresses) would
+    // otherwise be hoisted out of the caller's tile loop and kept alive across the main loop -- ~50 registers the 256-VGPR
+    // kernel does not have; they were spilled (scratch stores that reached HBM: +25 MB written per launch, PMC WRITE_SIZE)
+    asm volatile("" : "+v"(lane));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1;
     const int li = lane & 31, kh = lane >> 5;
@@ -2349,18 +2354,16 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
     FLOWSE_WXB(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, w) FLOWSE_FENCE
 
     float4 dA[5], dB[5], bA[3][TN], bB[3][TN];
-    {
-        const int chunk = c_begin;
-        (void)chunk;
-        FLOWSE_WLOADB(0, 0, c_begin, bA)
-    }
+    // first weight fragments of a tile: requested here for the block's first tile and again right after a tile's output
+    // stage (not before it: 24 registers that would have to survive the stage)
+    auto first_weights = [&]() { FLOWSE_WLOADB(0, 0, c_begin, bA) };
+    first_weights();
     // ---- tiles of this block.  The staging pipeline runs ACROSS tile boundaries: during a tile's last chunk the halo of
     // the NEXT tile's first chunk (and its first weight fragments) are requested, normalised and written to the idle LDS
     // buffer exactly like any other "next chunk", so only the block's first tile pays a prologue (tpb > 1 needs an even
     // number of chunks: every tile then starts in buffer 0, and the output stage lives behind it, see launch_f43).
     for (int ti = 0; ti < tpb; ++ti) {
     const bool more = ti + 1 < tpb;
-    const F43Tile nxt = more ? make_tile(mg * tpb + ti + 1) : cur;
     const int y0 = cur.y0, x0 = cur.x0, ty = cur.ty, tx = cur.tx;
     const int m_tl = (b * H + y0) * W + x0;
     (void)ty; (void)tx;
@@ -2374,7 +2377,8 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
         const float* Hcur = Hs + ((chunk - c_begin) & 1) * HBUF;
         const bool wrap = chunk + 1 >= c_end;            // the tile's last chunk stages for the block's next tile
         const int cnext = wrap ? (more ? c_begin : c_end - 1) : chunk + 1, nbuf = (chunk - c_begin + 1) & 1;
-        const F43Tile& stile = (wrap && more) ? nxt : cur;
+        // (the next tile's state is derived here, for the one chunk that needs it: nothing extra stays live in the loop)
+        const F43Tile stile = (wrap && more) ? make_tile(mg * tpb + ti + 1) : cur;
         FLOWSE_WLOADA(0, 0, dA)
         FLOWSE_WXA(dA) FLOWSE_WXB(dA)
         FLOWSE_FENCE
@@ -2396,7 +2400,8 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
         FLOWSE_WPHASE(dA, bA, 2, 1, chunk, dB, bB, -1, -1)
         FLOWSE_WPHASE(dB, bB, 2, 2, chunk, dA, bA, -1, -1)
         FLOWSE_WPHASE(dA, bA, 2, 3, chunk, dB, bB, -1, -1)
-        FLOWSE_WLOADB(0, 0, cnext, bA) FLOWSE_FENCE       // first weights of the next chunk
+        if (!wrap) { FLOWSE_WLOADB(0, 0, cnext, bA) }
+        FLOWSE_FENCE                                      // first weights of the next chunk
         FLOWSE_WMMA3(dB, bB, x) FLOWSE_WMMA3(dB, bB, y) FLOWSE_WMMA3(dB, bB, z) FLOWSE_WMMA3(dB, bB, w)
         FLOWSE_FENCE
 #else
@@ -2415,7 +2420,8 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
         FLOWSE_WPHASE(dA, bA, 2, 1, chunk, dB, bB, -1, -1)
         FLOWSE_WPHASE(dB, bB, 2, 2, chunk, dA, bA, 3, -1)
         FLOWSE_WPHASE(dA, bA, 2, 3, chunk, dB, bB, 4, -1)
-        FLOWSE_WLOADB(0, 0, cnext, bA) FLOWSE_FENCE       // first weights of the next chunk
+        if (!wrap) { FLOWSE_WLOADB(0, 0, cnext, bA) }     // first weights of the next chunk (a next TILE's: after the output stage)
+        FLOWSE_FENCE
         FLOWSE_WMMA3(dB, bB, x) FLOWSE_FENCE
         if (GN) xform1(5);
         FLOWSE_FENCE
@@ -2497,7 +2503,10 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
         const int tile_ix = ty * tiles_x + tx;           // row-major index of this 8 x 16 tile in the sample's tile grid
         // the exchange region sits BEHIND halo buffer 0, which already holds the next tile's first chunk (tpb > 1)
         f43_out_exchange<CH>(a, acc, smem + HBUF, b, y0, x0, n0, tile_ix);
-        if (more) __syncthreads();                       // buffer 1 (under the exchange region) is written again in the next tile
+        if (more) {
+            first_weights();
+            __syncthreads();                             // buffer 1 (under the exchange region) is written again in the next tile
+        }
     } else {
         // C tile of all 64 TN channels ([128][64 TN + 4] floats): with TN = 2 both channel groups scatter at once (two
         // waves per pass instead of one), then the output stage runs over the two 64-channel halves back to back
@@ -2533,7 +2542,7 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
         }
     }
 #endif
-    cur = nxt;
+    if (more) cur = make_tile(mg * tpb + ti + 1);
     }   // tiles of this block
 }
 
