@@ -778,11 +778,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
         for (int q = 0; q < A_LOADS; ++q) {
             const bool ok = (tapmask[q] >> tap) & 1u;
             const unsigned vo = ok ? (second ? avo2[q] : avo1[q]) : OOB;
+#ifdef FLOWSE_PROBE_FLAT_NOA     /* measurement probes (results garbage): no activation / no weight loads in the flat kernel */
+            ra[R][q] = u32x4{vo, soff_a, (unsigned)s, 0x3f800000u};
+#else
             ra[R][q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, vo, soff_a, 0)
                               : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, vo, soff_a, 0);
+#endif
         }
 #pragma unroll
-        for (int q = 0; q < B_LOADS; ++q) rb[R][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo[q], soff_b, 0);
+        for (int q = 0; q < B_LOADS; ++q)
+#ifdef FLOWSE_PROBE_FLAT_NOB
+            rb[R][q] = u32x4{bvo[q], soff_b, (unsigned)s, 0x3f800000u};
+#else
+            rb[R][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo[q], soff_b, 0);
+#endif
     };
     auto lstore = [&](int buf, auto ring) {
         constexpr int R = decltype(ring)::value;
@@ -858,6 +867,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_fast_kernel(ConvArg
         if (s + 2 < S) lstore(0, R0{});
         __syncthreads();
     }
+#ifdef FLOWSE_PROBE_FLAT_NOEPI   /* measurement probe: no output stage */
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) a.out[m0] = t;
+        return;
+    }
+#endif
     conv_epilogue<WM, WN, TM, TN, OT>(a, acc, smem, m0, n0, M, HW, split);
 }
 
