@@ -16,23 +16,27 @@ TOL = 1e-3          # north_star bar
 TIGHT = 1e-4        # what the fp32 MFMA path is expected to reach
 
 
-def _model(cfg, tag=None, graph=False):
-    """graph=True: a handle that replays its launch list as a hipGraph (opt-in, FLOWSE_GRAPH=1 is read when the handle is
-    created; the default is eager launches, which measure faster on MI355X)."""
+def _model(cfg, tag=None, graph=False, branch=False):
+    """graph=True: a handle that replays its launch list as a hipGraph; branch=True: the shortcut conv of a ResnetBlock on
+    a second stream.  Both are opt-in (FLOWSE_GRAPH=1 / FLOWSE_BRANCH=1, read when the handle is created): the default --
+    eager launches on one stream -- measures faster on MI355X."""
     import os
     from flowmse_amd.model import VFModel
-    old = os.environ.get("FLOWSE_GRAPH")
-    if graph:
-        os.environ["FLOWSE_GRAPH"] = "1"
-    else:
-        os.environ.pop("FLOWSE_GRAPH", None)
+    want = {"FLOWSE_GRAPH": graph, "FLOWSE_BRANCH": branch}
+    old = {k: os.environ.get(k) for k in want}
+    for k, on in want.items():
+        if on:
+            os.environ[k] = "1"
+        else:
+            os.environ.pop(k, None)
     try:
         m = VFModel(backbone="ncsnpp", ode="flowmatching", **cfg)
     finally:
-        if old is None:
-            os.environ.pop("FLOWSE_GRAPH", None)
-        else:
-            os.environ["FLOWSE_GRAPH"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     names = [n for n, _ in m.dnn.named_parameters()]
     sd = {n: torch.from_numpy(synth.synth_param(n, tuple(p.shape))) for n, p in m.dnn.named_parameters()}
     m.dnn.load_state_dict(sd)
@@ -458,7 +462,12 @@ def test_graph_replay_equals_eager_launches():
     assert C.rel_l2(got.cpu(), g["x_N5"]) < TIGHT
     assert tiny.dnn.graph_launches() > 0 and eager_model.dnn.graph_launches() == 0
     want = get_white_box_solver("euler", eager_model.ode, eager_model, Y=Y, N=5, z=Z)()[0]
-    assert torch.equal(got, want), "graph replay and eager two-stream launches differ"
+    assert torch.equal(got, want), "graph replay and eager launches differ"
+    # the two-stream form (shortcut conv forked onto a side stream, joined before Conv_1), eager and captured
+    for kw in (dict(branch=True), dict(branch=True, graph=True)):
+        mb = _model(C.TINY, **kw)
+        outs = [get_white_box_solver("euler", mb.ode, mb, Y=Y, N=5, z=Z)()[0].clone() for _ in range(3)]
+        assert all(torch.equal(o, want) for o in outs), f"two-stream launch list {kw} differs from the single-stream one"
 
 
 def test_graphs_really_replay_on_the_default_and_on_side_streams():
