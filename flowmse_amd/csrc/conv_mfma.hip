@@ -2200,8 +2200,15 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
     auto hload = [&](const F43Tile& t, int chunk, int Q) -> u32x4 {
         const int c0 = chunk * KC;
         const bool second = c0 >= C1;
+#ifdef FLOWSE_PROBE_BLOCKED_HALO   /* measurement probe (results garbage): address the halo AS IF activations were stored */
+        /* channel-chunk-major [C/32][H][W][32] -- a halo row of a chunk is then 18 x 128 contiguous bytes instead of 18     */
+        /* pieces of 128 bytes at a pitch of C x 4 bytes; same number of loads, same bytes                                    */
+        const unsigned cs = 32u;
+        const unsigned soff = (t.woff * 32u + (unsigned)((second ? c0 - C1 : c0) >> 5) * (unsigned)HW * 32u) * 4u;
+#else
         const unsigned cs = (unsigned)(second ? C2 : C1);
         const unsigned soff = (t.woff * cs + (unsigned)(second ? c0 - C1 : c0)) * 4u;
+#endif
         const unsigned off = ((t.hin >> Q) & 1u) ? (hpix[Q] * cs + (unsigned)col4 * 4u) * 4u : OOB;
         return second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, soff, 0)
                       : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, soff, 0);
