@@ -64,15 +64,31 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const float* 
         const bool kok = krow < L;
         const float* kp = base + (int64_t)(kok ? krow : 0) * rs + C + kh * 4;
         const float* qp = Qs + li * QROW + kh * 4;
-#pragma unroll 4
-        for (int j = 0; j < C / 8; ++j) {
-            float4 a = *reinterpret_cast<const float4*>(kp + j * 8);
-            if (!kok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 q = *reinterpret_cast<const float4*>(qp + j * 8);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q.x, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q.y, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q.z, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q.w, s, 0, 0, 0);
+        // The loop is one chain of dependent MFMAs, so a load inside it is a full L2 round trip that nothing hides: the key
+        // row runs through a ring of four quads, each requested four iterations (16 MFMAs = 1 024 cycles) ahead of its use.
+        constexpr int NQ = C / 8;
+        float4 ak[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ak[u] = u < NQ ? *reinterpret_cast<const float4*>(kp + u * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!kok) ak[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll 1
+        for (int g = 0; g < NQ; g += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = g + u;
+                const float4 a = ak[u];
+                if (j + 4 < NQ) {
+                    ak[u] = *reinterpret_cast<const float4*>(kp + (j + 4) * 8);
+                    if (!kok) ak[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                const float4 q = *reinterpret_cast<const float4*>(qp + j * 8);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q.x, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q.y, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q.z, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q.w, s, 0, 0, 0);
+            }
         }
         // ---- online softmax over keys (rows of S^T); this lane's query = li
         float mx = -INFINITY;
@@ -99,12 +115,15 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const float* 
         for (int t = 0; t < NCT; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            float vv[16];                       // the channel tile's 16 V rows, requested together
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 const float v = base[(int64_t)(key < L ? key : 0) * rs + 2 * C + t * 32 + li];
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(key < L ? v : 0.f, s[r], o[t], 0, 0, 0);
+                vv[r] = key < L ? v : 0.f;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[r], s[r], o[t], 0, 0, 0);
         }
     }
     // ---- merge the per-wave states: m = max_w m_w, O = sum_w O_w e^{m_w - m}, l = sum_w l_w e^{m_w - m}

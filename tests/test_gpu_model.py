@@ -534,6 +534,16 @@ def test_bench_spawns_its_own_ranks():
     assert out["n_gpus"] == 2 and len(out["per_rank_ms_per_step"]) == 2 and out["value"] > 0
     assert out["config"]["global_batch"] == 2
     assert out["config"]["collective_backend"] == ("nccl" if two else "gloo")
+    # BASELINE config[3] through the same launcher: 12 ragged utterances sharded over the two ranks, final gather to rank 0
+    cmd3 = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "vbdmd", "--utts", "12", "--steps", "1",
+            "--warmup", "1", "--batch", "4", "--nsolver", "2"]
+    r3 = subprocess.run(cmd3, env=env, capture_output=True, text=True, timeout=800)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    o3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.startswith("{")][-1])
+    assert o3["n_gpus"] == 2 and o3["scaling"] == "strong" and o3["config"]["utterances"] == 12
+    pr = o3["per_rank"]
+    assert len(pr["frames"]) == 2 and sum(pr["frames"]) == o3["config"]["frames_padded_total"] and min(pr["utterances"]) >= 1
+    assert o3["value"] > 0 and pr["frame_imbalance_max_over_mean"] < 1.5
     if not two:                              # without the hook the same command must refuse, not measure one GPU
         env2 = {k: v for k, v in os.environ.items() if not k.startswith("FLOWSE_BENCH")}
         r2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=800)
