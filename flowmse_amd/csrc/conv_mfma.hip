@@ -2639,10 +2639,413 @@ bool conv_f43_wide(int B, int H, int W, int Cout) {
     return !conv_f43_forced_bn64() && (Cout % 128) == 0 && ((int64_t)B * H * W / 128) * (Cout / 128) >= 512;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// F(4,3), producer / consumer form (FLOWSE_F43_PC=1; 128-output-channel layers with >= 8 tiles per CU, i.e. the 256 x 256
+// level).  profiles/r03_f43_probes.md: the waves that wait for weight fragments must not issue the halo loads (vector
+// loads return in issue order: -6...8 % without them), and the output stage is worth 11 %.  Here ONE persistent block
+// per CU has eight waves: four MFMA waves (wn, CH as in conv3x3_f43_kernel) that only read operands (halo from LDS,
+// weights from L2) and issue MFMAs, and four LOADER waves that stage every halo (request, GroupNorm + SiLU, LDS write)
+// one chunk ahead and run the whole output stage from an LDS dump of the accumulators while the MFMA waves are already
+// in the next tile.  One register allocation per kernel (256) is why this is one block per CU and not two.
+//   step g (one 32-channel chunk of one tile; all eight waves meet at ONE barrier per step):
+//     MFMA waves   twelve k-block phases on halo buffer g & 1; after a tile's last chunk: accumulators -> D (24
+//                  ds_write_b128 per lane), accumulators = 0
+//     loader waves request halo g + 1; output stage of the tile dumped at the end of step g - 1 (first half) / g - 2
+//                  (second half); GroupNorm of halo g + 1 -> buffer (g + 1) & 1
+// LDS: 2 halo buffers (52 KB) + D (4 waves x 24 KB): 148 KB.  The loaders' transposition scratch is the part of D they
+// have just read.
+constexpr int F43PC_D_FLOATS = 4 * 3 * 2 * 1024;              // [mfma wave][component][channel tile][4 reg quads][64 lanes][4]
+
+template <int CH>
+__device__ __forceinline__ void f43pc_mfma_waves(const ConvArgs& a, float* smem, int steps, int nchunks) {
+    constexpr int TN = 2;
+    constexpr int HBUF = 10 * F43_HROW;
+    float* Hs = smem;
+    float* D = smem + 2 * HBUF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3
+    const int wn = wave & 1;
+    const int li = lane & 31, kh = lane >> 5;
+    const int Cin = a.C1 + a.C2;
+    const int abase = (4 * (li >> 4) + CH) * F43_HROW + (li & 15) * LDS_ROW + kh * 4;
+    const __amdgpu_buffer_rsrc_t rsrcw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wino), 0, a.Cout * 18 * Cin * 4, 0x00020000);
+    const unsigned wslice = (unsigned)(wn * TN) * 3u * (unsigned)nchunks;     // n0 = 0: one 128-channel block per layer
+    const unsigned wvo = (unsigned)lane * 16u + (unsigned)CH * 3u * 4096u;
+    f32x16 acc[3][TN];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+#define PC_FENCE __builtin_amdgcn_sched_barrier(0);
+#define PC_LOADA(KX, J, DD)                                                                                          \
+    {                                                                                                                \
+        const float* Ha = Hcur + abase + (KX) * LDS_ROW + (J) * 8;                                                   \
+        _Pragma("unroll") for (int r = 0; r < 5; ++r) DD[r] = *reinterpret_cast<const float4*>(Ha + r * F43_HROW);   \
+    }
+#define PC_LOADB(KX, J, CHK, BF)                                                                                     \
+    {                                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                             \
+            const unsigned so = (wslice + (unsigned)(3 * j + (KX)) * (unsigned)nchunks + (unsigned)(CHK)) * 24576u;  \
+            _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                          \
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, wvo + (c * 4 + (J)) * 1024, so, 0);     \
+                BF[c][j] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z),            \
+                                       __uint_as_float(t.w));                                                        \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+#define PC_H2(Q, H) (*reinterpret_cast<f32x2*>(&(Q).x + 2 * (H)))
+#define PC_XA(DD)                                                                                                    \
+    {                                                                                                                \
+        const f32x2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f};                                                             \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                              \
+            const f32x2 r0 = PC_H2(DD[0], h), r2 = PC_H2(DD[2], h), r4 = PC_H2(DD[4], h);                            \
+            const f32x2 v = __builtin_elementwise_fma(c4, r0, __builtin_elementwise_fma(cm5, r2, r4));               \
+            if (CH == 0) PC_H2(DD[0], h) = v;                                                                        \
+            else PC_H2(DD[4], h) = v;                                                                                \
+        }                                                                                                            \
+    }
+#define PC_XB(DD)                                                                                                    \
+    {                                                                                                                \
+        const f32x2 c4 = {4.f, 4.f}, cm4 = {-4.f, -4.f}, c2 = {2.f, 2.f}, cm2 = {-2.f, -2.f};                        \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                              \
+            const f32x2 r0 = PC_H2(DD[0], h), r1 = PC_H2(DD[1], h), r2 = PC_H2(DD[2], h), r3 = PC_H2(DD[3], h),      \
+                        r4 = PC_H2(DD[4], h);                                                                        \
+            if (CH == 0) {                                                                                           \
+                PC_H2(DD[1], h) = __builtin_elementwise_fma(cm4, r1 + r2, r3 + r4);                                  \
+                PC_H2(DD[2], h) = __builtin_elementwise_fma(c4, r1 - r2, r4 - r3);                                   \
+            } else {                                                                                                 \
+                PC_H2(DD[1], h) = __builtin_elementwise_fma(c2, r2 - r0, r3 - r1);                                   \
+                PC_H2(DD[2], h) = __builtin_elementwise_fma(cm2, r2 - r0, r3 - r1);                                  \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+#define PC_MMA(V, BF, K)                                                                                             \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
+        acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[(c == 0 && CH == 1) ? 4 : c].K, BF[c][j].K, acc[c][j], 0, 0, 0);
+#define PC_PHASE(V, BF, NKX, NJ, NCHK, DN, BFN)                                                                      \
+    PC_LOADA(NKX, NJ, DN) PC_LOADB(NKX, NJ, NCHK, BFN) PC_FENCE                                                      \
+    PC_MMA(V, BF, x) PC_FENCE PC_MMA(V, BF, y) PC_FENCE                                                              \
+    PC_XA(DN) PC_FENCE PC_MMA(V, BF, z) PC_FENCE                                                                     \
+    PC_XB(DN) PC_FENCE PC_MMA(V, BF, w) PC_FENCE
+    float4 dA[5], dB[5], bA[3][TN], bB[3][TN];
+    PC_LOADB(0, 0, 0, bA)
+    __syncthreads();                                             // halo of step 0 is staged
+    int chunk = 0;
+    for (int g = 0; g < steps; ++g) {
+        const float* Hcur = Hs + (g & 1) * HBUF;
+        const int cnext = chunk + 1 < nchunks ? chunk + 1 : 0;
+        PC_LOADA(0, 0, dA)
+        PC_XA(dA) PC_XB(dA)
+        PC_FENCE
+        PC_PHASE(dA, bA, 0, 1, chunk, dB, bB)
+        PC_PHASE(dB, bB, 0, 2, chunk, dA, bA)
+        PC_PHASE(dA, bA, 0, 3, chunk, dB, bB)
+        PC_PHASE(dB, bB, 1, 0, chunk, dA, bA)
+        PC_PHASE(dA, bA, 1, 1, chunk, dB, bB)
+        PC_PHASE(dB, bB, 1, 2, chunk, dA, bA)
+        PC_PHASE(dA, bA, 1, 3, chunk, dB, bB)
+        PC_PHASE(dB, bB, 2, 0, chunk, dA, bA)
+        PC_PHASE(dA, bA, 2, 1, chunk, dB, bB)
+        PC_PHASE(dB, bB, 2, 2, chunk, dA, bA)
+        PC_PHASE(dA, bA, 2, 3, chunk, dB, bB)
+        PC_LOADB(0, 0, cnext, bA) PC_FENCE
+        PC_MMA(dB, bB, x) PC_MMA(dB, bB, y) PC_MMA(dB, bB, z) PC_MMA(dB, bB, w)
+        PC_FENCE
+        if (cnext == 0) {                                        // tile finished: hand the accumulators to the loader waves
+            float* Dw = D + wave * (3 * 2 * 1024);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        *reinterpret_cast<float4*>(Dw + ((c * 2 + j) * 4 + q) * 256 + lane * 4) =
+                            make_float4(acc[c][j][4 * q], acc[c][j][4 * q + 1], acc[c][j][4 * q + 2], acc[c][j][4 * q + 3]);
+                        acc[c][j][4 * q] = acc[c][j][4 * q + 1] = acc[c][j][4 * q + 2] = acc[c][j][4 * q + 3] = 0.f;
+                    }
+        }
+        chunk = cnext;
+        __syncthreads();
+    }
+    __syncthreads();                                             // the loaders' two drain steps
+    __syncthreads();
+#undef PC_FENCE
+#undef PC_LOADA
+#undef PC_LOADB
+#undef PC_H2
+#undef PC_XA
+#undef PC_XB
+#undef PC_MMA
+#undef PC_PHASE
+}
+
+template <int GN>
+__device__ __forceinline__ void f43pc_loader_waves(const ConvArgs& a, float* smem, int tile0, int ntile, int nchunks) {
+    constexpr int HBUF = 10 * F43_HROW, HROWS = 180, H_LOADS = 6;
+    float* Hs = smem;
+    float* D = smem + 2 * HBUF;
+    const int tl = threadIdx.x - 256;                            // 0..255 over the four loader waves
+    const int lane = tl & 63;
+    const int lw = __builtin_amdgcn_readfirstlane(tl >> 6);      // 0..3: output stage of channel group wn = lw & 1, tile j = lw >> 1
+    const int H = a.H, W = a.W, HW = H * W;
+    const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2, Cout = a.Cout;
+    const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 3);
+    const int col4 = tl & 7, row0 = tl >> 3;
+    unsigned hpix[H_LOADS];
+    int hlds[H_LOADS];
+#pragma unroll
+    for (int q = 0; q < H_LOADS; ++q) {
+        const int hr = row0 + 32 * q;
+        const int hy = hr / 18, hx = hr - hy * 18;
+        hpix[q] = (unsigned)(hy * W + hx);
+        hlds[q] = hr < HROWS ? hy * F43_HROW + hx * LDS_ROW + col4 * 4 : -1;
+    }
+    const int b = tile0 / tiles_img;                             // all tiles of a block lie in one sample (launch_f43pc)
+    const int64_t sbase = (int64_t)b * HW - W - 1;
+    const int spix = HW + 2 * W + 2;
+    const __amdgpu_buffer_rsrc_t rsrc1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1 + sbase * C1), 0, spix * C1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(C2 ? a.in2 + sbase * C2 : a.in1), 0, C2 ? spix * C2 * 4 : 0, 0x00020000);
+    auto tile_xy = [&](int mt, int& ty, int& tx) {
+        const int tt = mt - b * tiles_img;
+        if ((tiles_x & 3) == 0) {
+            const int per_strip = 4 * (H >> 3);
+            const int strip = tt / per_strip, w = tt - strip * per_strip;
+            ty = w >> 2;
+            tx = strip * 4 + (w & 3);
+        } else {
+            ty = tt / tiles_x;
+            tx = tt - ty * tiles_x;
+        }
+    };
+    u32x4 rh[H_LOADS];
+    unsigned hin = 0;
+    // request the halo of (tile index ti, chunk): registers only
+    auto request = [&](int ti, int chunk) {
+        int ty, tx;
+        tile_xy(tile0 + ti, ty, tx);
+        const int y0 = ty * 8, x0 = tx * 16;
+        hin = 0;
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            const int hr = row0 + 32 * q;
+            const int hy = hr / 18, hx = hr - hy * 18;
+            const bool in = hr < HROWS && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+            hin |= in ? (1u << q) : 0u;
+        }
+        const unsigned woff = (unsigned)(y0 * W + x0);
+        const int c0 = chunk * KC;
+        const bool second = c0 >= C1;
+        const unsigned cs = (unsigned)(second ? C2 : C1);
+        const unsigned soff = (woff * cs + (unsigned)(second ? c0 - C1 : c0)) * 4u;
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            const unsigned off = ((hin >> q) & 1u) ? (hpix[q] * cs + (unsigned)col4 * 4u) * 4u : OOB;
+            rh[q] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, soff, 0)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, soff, 0);
+        }
+    };
+    // GroupNorm + SiLU of the requested halo, into halo buffer `buf`
+    auto deliver = [&](int chunk, int buf) {
+        float4 g_mu = make_float4(0.f, 0.f, 0.f, 0.f), g_sc = g_mu, g_be = g_mu;
+        if (GN) {
+            const int cg = chunk * KC + col4 * 4;
+            g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
+            g_sc = *reinterpret_cast<const float4*>(a.gn.scale + (int64_t)b * Cin + cg);
+            g_be = *reinterpret_cast<const float4*>(a.gn.beta + cg);
+        }
+        float* Hb = Hs + buf * HBUF;
+#pragma unroll
+        for (int q = 0; q < H_LOADS; ++q) {
+            u32x4 v = rh[q];
+            if (GN) v = gn_quad<GN>(v, g_mu, g_sc, g_be, (hin >> q) & 1u);
+            if (hlds[q] >= 0) *reinterpret_cast<u32x4*>(Hb + hlds[q]) = v;
+        }
+    };
+    // ---- output stage state (lane mapping of the MFMA C/D layout, as dumped)
+    const int li = lane & 31, kh = lane >> 5;
+    const int wn = lw & 1, jt = lw >> 1;
+    const int pl = lane >> 3, cq = lane & 7;
+    const int ch0 = wn * 64 + jt * 32;
+    float o[4][16];
+    float4 piv = make_float4(0.f, 0.f, 0.f, 0.f), s1 = piv, s2 = piv;
+    int roff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int pp = i * 8 + pl;
+        roff[i] = ((pp >> 4) * W + (pp & 15)) * Cout;
+    }
+    const bool has_res = a.res != nullptr;
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + ch0 + cq * 4);
+    if (a.bias2) {
+        const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)b * a.bias2_stride + ch0 + cq * 4);
+        bq.x += t.x; bq.y += t.y; bq.z += t.z; bq.w += t.w;
+    }
+    const float scale = a.scale;
+    // part 0: read the six components of this wave's 32 channels, form the four output rows, first row quad of the tile;
+    // part 1: second row quad, statistics
+    auto out_part = [&](int ti, int part) {
+        int ty, tx;
+        tile_xy(tile0 + ti, ty, tx);
+        const int64_t pix0 = ((int64_t)b * H + ty * 8 + 4 * part) * W + tx * 16;
+        const float* resb = a.res + pix0 * Cout + ch0 + cq * 4;
+        float* outb = a.out + pix0 * Cout + ch0 + cq * 4;
+        float4 rres[8];
+        if (has_res) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rres[i] = *reinterpret_cast<const float4*>(resb + roff[i]);
+        }
+        const float* D0 = D + (0 * 2 + wn) * (3 * 2 * 1024);     // MFMA wave (wn, CH 0): m0, m1, m2
+        const float* D1 = D + (1 * 2 + wn) * (3 * 2 * 1024);     // MFMA wave (wn, CH 1): m5, m3, m4
+        if (part == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 m[6];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    m[c] = *reinterpret_cast<const float4*>(D0 + ((c * 2 + jt) * 4 + q) * 256 + lane * 4);
+                    m[3 + c] = *reinterpret_cast<const float4*>(D1 + ((c * 2 + jt) * 4 + q) * 256 + lane * 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float m0 = (&m[0].x)[e], m1 = (&m[1].x)[e], m2 = (&m[2].x)[e];
+                    const float m5 = (&m[3].x)[e], m3 = (&m[4].x)[e], m4 = (&m[5].x)[e];
+                    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                    const int r = 4 * q + e;
+                    o[0][r] = (m0 + s12) + s34;
+                    o[1][r] = fmaf(2.f, d34, d12);
+                    o[2][r] = fmaf(4.f, s34, s12);
+                    o[3][r] = fmaf(8.f, d34, d12) + m5;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // transposition scratch [64 px][32 ch] = two 4 KB blocks of D that only this wave reads and has read: components
+        // 0 and 1 of (wn, CH 0, tile jt) hold pixels 0-31 and 32-63
+        float* Tlo = const_cast<float*>(D0) + (0 * 2 + jt) * 1024;
+        float* Thi = const_cast<float*>(D0) + (1 * 2 + jt) * 1024;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * part + e;
+                (k < 2 ? Tlo : Thi)[((k & 1) * 16 + (e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + li] = o[k][r];
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pp = i * 8 + pl;
+            float4 v = *reinterpret_cast<const float4*>((i < 4 ? Tlo : Thi) + (pp & 31) * 32 + cq * 4);
+            v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+            if (has_res) { v.x += rres[i].x; v.y += rres[i].y; v.z += rres[i].z; v.w += rres[i].w; }
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            *reinterpret_cast<float4*>(outb + roff[i]) = v;
+            if (part == 0 && i == 0) { piv = v; s1 = s2 = make_float4(0.f, 0.f, 0.f, 0.f); }
+            const float dx = v.x - piv.x, dy = v.y - piv.y, dz = v.z - piv.z, dw = v.w - piv.w;
+            s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+            s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
+        }
+        if (part == 0 || !a.stats) return;
+        float mean[4] = {piv.x + s1.x * (1.f / 16), piv.y + s1.y * (1.f / 16), piv.z + s1.z * (1.f / 16), piv.w + s1.w * (1.f / 16)};
+        float m2[4] = {fmaxf(s2.x - s1.x * s1.x * (1.f / 16), 0.f), fmaxf(s2.y - s1.y * s1.y * (1.f / 16), 0.f),
+                       fmaxf(s2.z - s1.z * s1.z * (1.f / 16), 0.f), fmaxf(s2.w - s1.w * s1.w * (1.f / 16), 0.f)};
+        float cnt = 16.f;
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float mo = __shfl_xor(mean[e], off), qo = __shfl_xor(m2[e], off);
+                const float d = mo - mean[e];
+                m2[e] = m2[e] + qo + d * d * (0.5f * cnt);
+                mean[e] = 0.5f * (mean[e] + mo);
+            }
+            cnt *= 2.f;
+        }
+        if (pl == 0) {
+            const int tile_ix = ty * tiles_x + tx;
+            float* dst = a.stats + (((int64_t)b * a.stats_nblk + tile_ix) * Cout + ch0 + cq * 4) * 2;
+            *reinterpret_cast<float4*>(dst) = make_float4(mean[0], m2[0], mean[1], m2[1]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(mean[2], m2[2], mean[3], m2[3]);
+        }
+    };
+    const int steps = ntile * nchunks;
+    request(0, 0);
+    deliver(0, 0);
+    __syncthreads();
+    int chunk = 0, ti = 0;
+    for (int g = 0; g < steps; ++g) {
+        // what the MFMA waves compute now: (ti, chunk); stage (ti', chunk') = the next step's
+        int cn = chunk + 1, tn = ti;
+        if (cn == nchunks) { cn = 0; ++tn; }
+        const bool more = g + 1 < steps;
+        if (more) request(tn, cn);
+        if (ti > 0 && chunk == 0) out_part(ti - 1, 0);
+        if (ti > 0 && chunk == 1) out_part(ti - 1, 1);
+        if (more) deliver(cn, (g + 1) & 1);
+        chunk = cn;
+        ti = tn;
+        __syncthreads();
+    }
+    out_part(ntile - 1, 0);
+    __syncthreads();
+    out_part(ntile - 1, 1);
+    __syncthreads();
+}
+
+template <int GN>
+__global__ __launch_bounds__(512, 2) void conv3x3_f43pc_kernel(ConvArgs a, int tpb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nchunks = (a.C1 + a.C2) / KC;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= 4) f43pc_loader_waves<GN>(a, smem, bid * tpb, tpb, nchunks);
+    else if (wave >= 2) f43pc_mfma_waves<1>(a, smem, tpb * nchunks, nchunks);
+    else f43pc_mfma_waves<0>(a, smem, tpb * nchunks, nchunks);
+}
+
+// FLOWSE_F43_PC=1 and: one 128-channel block per layer, tiles divisible over 256 persistent blocks with >= 8 tiles each,
+// all of a block's tiles in one sample, >= 4 chunks
+static bool f43pc_ok(const ConvArgs& a, int* tpb) {
+    static const bool on = getenv("FLOWSE_F43_PC") != nullptr;
+    if (!on || a.partial || a.Cout != 128) return false;
+    const int64_t tiles = (int64_t)a.B * a.H * a.W / 128, tiles_img = (int64_t)a.H * a.W / 128;
+    const int nch = (a.C1 + a.C2) / KC;
+    if (tiles % 256 != 0 || nch < 4) return false;
+    const int64_t t = tiles / 256;
+    if (t < 8 || tiles_img % t != 0) return false;
+    *tpb = (int)t;
+    return true;
+}
+
+static int launch_f43pc(const ConvArgs& a, int tpb, hipStream_t s) {
+    const size_t lds = (2 * 10 * F43_HROW + F43PC_D_FLOATS) * sizeof(float);
+    const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;
+    const int grid = (int)((int64_t)a.B * a.H * a.W / 128 / tpb);
+#define FLOWSE_LPC(G)                                                                               \
+    {                                                                                               \
+        if (const int rc = allow_lds<&conv3x3_f43pc_kernel<G>>(lds)) return rc;                     \
+        hipLaunchKernelGGL((conv3x3_f43pc_kernel<G>), dim3(grid), dim3(512), lds, s, a, tpb);       \
+    }
+    if (gn == 2) FLOWSE_LPC(2) else if (gn == 1) FLOWSE_LPC(1) else FLOWSE_LPC(0)
+#undef FLOWSE_LPC
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
 static int launch_f43(const ConvArgs& a, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int ks = a.ksplit > 1 ? a.ksplit : 1;       // slices of 32-channel chunks (gridDim.y), see wino_plan
     const bool wide = !a.partial && conv_f43_wide(a.B, a.H, a.W, a.Cout);
+    {
+        int pc_tpb = 0;
+        if (wide && f43pc_ok(a, &pc_tpb)) return launch_f43pc(a, pc_tpb, s);
+    }
     // Tiles per block of the 128-channel form: as many (4, 2) as still leave two full rounds of 512 blocks (256 CUs x 2),
     // so that the prologue -- first halo from HBM, its GroupNorm, first weights, ~14 % of a one-tile block's life -- is
     // paid once per block instead of once per tile.  Needs an even chunk count (every tile starts in halo buffer 0).

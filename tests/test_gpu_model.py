@@ -608,3 +608,50 @@ def test_rejects_cpu_and_bad_shapes(tiny):
     from flowmse_amd._lib import FlowseError
     with pytest.raises(FlowseError):
         tiny(xt[..., :50].cuda().contiguous(), torch.ones(2).cuda(), y[..., :50].cuda().contiguous())   # T % 4 != 0
+
+
+_PC_CHILD = """
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import numpy as np, torch
+import _cases as C
+from flowmse_amd.util import synth
+from flowmse_amd.model import VFModel
+m = VFModel(backbone="ncsnpp", ode="flowmatching", **C.FULL)
+m.dnn.load_state_dict({{n: torch.from_numpy(synth.synth_param(n, tuple(p.shape))) for n, p in m.dnn.named_parameters()}})
+m = m.cuda().eval()
+B, T = 8, 256
+y = torch.cat([C.c64(synth.synth_spectrogram(i, 1, 256, T)) for i in range(B)]).cuda()
+x = torch.cat([C.c64(synth.synth_noise(i, 1, 256, T)) for i in range(B)]).cuda() * 0.487 + y
+t = torch.linspace(0.03, 1.0, B, device="cuda")
+out = m(x, t, y)
+torch.cuda.synchronize()
+np.save({dst!r}, torch.view_as_real(out[::3]).cpu().numpy())
+"""
+
+
+@pytest.mark.timeout(900)
+def test_f43_producer_consumer_kernel_equals_default(tmp_path):
+    """FLOWSE_F43_PC=1: the 256 x 256 level's 128-channel 3x3 convs run the persistent producer / consumer form (four MFMA
+    waves + four loader waves per CU, accumulators handed over through LDS).  Same arithmetic in the same order as the
+    default kernel: one network evaluation at the headline shape [8,1,256,256] must agree to rounding (the output
+    transform A^T m is summed in a different association)."""
+    import os
+    import subprocess
+    import sys
+    tests = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(tests)
+    outs = {}
+    for mode in ("default", "pc"):
+        dst = str(tmp_path / f"{mode}.npy")
+        env = {k: v for k, v in os.environ.items() if k != "FLOWSE_F43_PC"}
+        if mode == "pc":
+            env["FLOWSE_F43_PC"] = "1"
+        r = subprocess.run([sys.executable, "-c", _PC_CHILD.format(tests=tests, root=root, dst=dst)], env=env,
+                           capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[mode] = np.load(dst)
+    a, b = outs["default"], outs["pc"]
+    err = float(np.linalg.norm(a - b) / np.linalg.norm(a))
+    print("producer/consumer F(4,3) vs default: rel-L2", err)
+    assert np.isfinite(b).all() and err < 2e-6           # (measured: bit-identical -- same products, same order of sums)
