@@ -2372,10 +2372,18 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
     // instead of one (this schedule) did NOT recover it (447 vs 447 us): the wait is not a fixed latency one can cover
     // with 3 000 cycles but the tail of the HBM round trips of the 8 load batches a block issues per chunk, which gates
     // the chunk barrier.  FLOWSE_F43_HALO_EARLY selects round 2's schedule (A-B builds).
+    // ONE wait for all of this phase's weight fragments (requested a phase ago; the only younger loads are the ones just
+    // issued: 3 TN fragments, + 6 halo / GroupNorm-parameter loads in a halo phase) instead of one s_waitcnt per fragment
+#ifdef FLOWSE_F43_WAIT1
+#define FLOWSE_WAIT_B(HL) __builtin_amdgcn_s_waitcnt(0x0F70 | (((HL) >= 0 ? 3 * TN + 6 : 3 * TN) & 15));
+#else
+#define FLOWSE_WAIT_B(HL)
+#endif
 #define FLOWSE_WPHASE(V, BF, NKX, NJ, NCHK, DN, BFN, XQ, HL)                                                         \
     FLOWSE_WLOADA(NKX, NJ, DN) FLOWSE_WLOADB(NKX, NJ, NCHK, BFN)                                                     \
     if ((HL) >= 0) gloadH(stile, cnext, (HL) < 0 ? 0 : (HL));                                                        \
     FLOWSE_FENCE                                                                                                     \
+    FLOWSE_WAIT_B(HL)                                                                                                \
     FLOWSE_WMMA3(V, BF, x) FLOWSE_FENCE                                                                              \
     if (GN && (XQ) >= 0) xform1((XQ) < 0 ? 0 : (XQ));                                                                \
     FLOWSE_FENCE FLOWSE_WMMA3(V, BF, y) FLOWSE_FENCE                                                                 \
@@ -2468,6 +2476,7 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
 #undef FLOWSE_WXB
 #undef FLOWSE_WMMA3
 #undef FLOWSE_WPHASE
+#undef FLOWSE_WAIT_B
 #undef FLOWSE_FENCE
 #ifdef FLOWSE_E4
 #undef FLOWSE_E4
