@@ -13,6 +13,7 @@ The nn.Module here is only a parameter container (PyTorch = tensor container / w
 arithmetic operation of the forward pass runs in hand-written HIP kernels behind the C ABI
 (include/flowse_hip.h).  There is no PyTorch / CPU fallback: CPU tensors raise.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -113,6 +114,8 @@ class NCSNpp(nn.Module):
         self.reset_parameters()
         self._uploaded_versions = None
         self._uploaded_device = None
+        self._frozen_depth = 0
+        self._frozen_checked = False
         self.precision = "fp32"
 
     # ------------------------------------------------------------------ initialisation (reference rules)
@@ -146,20 +149,24 @@ class NCSNpp(nn.Module):
 
     # ------------------------------------------------------------------ weights -> library
     def _params_in_order(self):
-        """Parameter objects in the library's table order.  The list is cached (the per-call cost of the sampler
-        plugins' VF_fn calls must stay at a version scan, not a module-tree walk) and rebuilt whenever a parameter
-        object was replaced (``_apply`` with tensor swapping, ``register_parameter``, ...)."""
+        """Parameter objects in the library's table order.  The list is cached (no module-tree walk per call) and
+        rebuilt whenever ANY parameter object was replaced (``_apply`` with tensor swapping, ``register_parameter``,
+        direct assignment, parametrize / prune, ...): the cache is validated by identity against the owning modules'
+        ``_parameters`` dicts -- one dict lookup per parameter, the same order of work as the version scan."""
         cached = self.__dict__.get("_plist")
-        if cached is not None and all(a is b for a, b in zip(cached[1], self._parameters_identity())):
-            return cached[0]
-        sd = dict(self.named_parameters())
-        plist = [sd[n] for n in self._param_names]
-        self.__dict__["_plist"] = (plist, self._parameters_identity())
+        if cached is not None:
+            plist, owners = cached
+            if all(o[0].get(o[1]) is q for o, q in zip(owners, plist)):
+                return plist
+        mods = dict(self.named_modules())
+        plist, owners = [], []
+        for n in self._param_names:
+            mod_name, _, leaf = n.rpartition(".")
+            m = mods[mod_name]
+            owners.append((m._parameters, leaf))
+            plist.append(m._parameters[leaf])
+        self.__dict__["_plist"] = (plist, owners)
         return plist
-
-    def _parameters_identity(self):
-        # two cheap witnesses that the module tree still holds the cached parameter objects
-        return (self.output_layer._parameters.get("weight"), self.all_modules[3]._parameters.get("weight"))
 
     def canonical_blob(self):
         """Flat float32 CPU tensor of all parameters in reference order / layout."""
@@ -180,16 +187,38 @@ class NCSNpp(nn.Module):
         """Force a weight re-upload before the next call (set by load_state_dict / .to() / precision changes; call it
         yourself after mutating parameters through ``.data`` -- such writes do not bump ``Parameter._version``)."""
         self._uploaded_versions = None
+        self._frozen_checked = False
 
     def _ensure_uploaded(self, device):
+        # inside `weights_frozen()` the O(#parameters) identity + version scan runs once, on the first call; later calls
+        # of the same loop only look at the dirty flag (mark_dirty / load_state_dict / _apply / set_precision reset it)
+        if self._frozen_depth > 0 and self._frozen_checked and self._uploaded_versions is not None \
+                and self._uploaded_device == device.index:
+            return
         if self._uploaded_versions is None or self._uploaded_device != device.index or \
                 self._uploaded_versions != [p._version for p in self._params_in_order()]:
             self.upload_weights(device)
+        self._frozen_checked = self._frozen_depth > 0
+
+    @contextlib.contextmanager
+    def weights_frozen(self):
+        """Promise that no parameter is mutated in place inside the block (a sampler loop: eval mode, ``no_grad``).
+        The per-call scan of all 647 ``Parameter._version`` counters then runs once instead of once per network
+        evaluation -- the per-NFE host cost of the plugin solver loop and of the black-box RK45 right-hand side.
+        Explicit invalidation (``mark_dirty``, ``load_state_dict``, ``.to()``, ``set_precision``, the EMA swap of
+        ``VFModel.eval``) is still honoured inside the block."""
+        self._frozen_depth += 1
+        self._frozen_checked = False
+        try:
+            yield self
+        finally:
+            self._frozen_depth -= 1
+            self._frozen_checked = False
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self.__dict__.pop("_plist", None)
-        self._uploaded_versions = None
+        self.mark_dirty()
         return r
 
     # ------------------------------------------------------------------ calls
@@ -263,7 +292,7 @@ class NCSNpp(nn.Module):
         """'fp32' (default, exact fp32 MFMA) | 'bf16x3' (split-bf16, fp32-class) | 'bf16' (BASELINE config 3)."""
         _lib.check(_lib.lib.flowse_model_set_precision(self._handle, self.PRECISIONS[mode]))
         self.precision = mode
-        self._uploaded_versions = None
+        self.mark_dirty()
         return self
 
     def profile_begin(self, mode=0):
@@ -279,7 +308,7 @@ class NCSNpp(nn.Module):
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self.__dict__.pop("_plist", None)
-        self._uploaded_versions = None
+        self.mark_dirty()
         return r
 
     def __del__(self):

@@ -87,10 +87,13 @@ def enhance_batch(model, ys, N=5, T_rev=1.0, t_eps=0.03, odesolver="euler"):
 def _write_wav(path, x, sr=16000):
     """16-bit PCM WAV like the reference's ``soundfile.write(path, x_hat, 16000)`` (evaluate.py:147; libsndfile's
     default subtype for .wav is PCM_16, float samples scaled by 0x7FFF and rounded to nearest).  soundfile itself is
-    used when importable, so output trees diff cleanly against the reference's.  Without it scipy writes the same
-    samples: libsndfile does NOT clip by default (SFC_SET_CLIPPING off), a sample with |x| > 1 -- possible after the
-    rescale by max|y| -- keeps the low 16 bits of its rounded value, and the fallback reproduces exactly that
-    wrap-around instead of saturating, so the two writers agree bit for bit on every input."""
+    used when importable, so output trees diff cleanly against the reference's.  Without it scipy writes samples formed
+    the way libsndfile forms them: the product ``x * 32767`` in float32 (libsndfile scales in the sample's own type
+    before ``lrintf``), round half to even, and -- libsndfile does NOT clip by default (SFC_SET_CLIPPING off) -- a
+    sample with |x| > 1, possible after the rescale by max|y|, keeps the low 16 bits of its rounded value instead of
+    saturating.  Non-finite samples (undefined in libsndfile's float -> int conversion) are written as 0.  The fallback
+    aims at the same file for finite input; it has not been diffed against libsndfile here (soundfile is not in
+    this image)."""
     x = np.asarray(x, dtype=np.float32)
     try:
         import soundfile
@@ -99,7 +102,9 @@ def _write_wav(path, x, sr=16000):
     except ImportError:
         pass
     from scipy.io import wavfile
-    pcm = np.rint(x.astype(np.float64) * 32767.0).astype(np.int64).astype(np.uint16).astype(np.int16)
+    scaled = np.rint(x * np.float32(32767.0))                      # float32 product, like libsndfile
+    scaled = np.where(np.isfinite(scaled), scaled, np.float32(0.0))
+    pcm = scaled.astype(np.int64).astype(np.uint16).astype(np.int16)
     wavfile.write(path, sr, pcm)
 
 

@@ -161,10 +161,12 @@ class VFModel(nn.Module):
                         self._ema_backup = [p.detach().clone() for p in self._ema_target]
                         for p, s in zip(self._ema_target, self._ema_shadow):
                             p.copy_(s.to(p.device))
+                        self.dnn.mark_dirty()
                 elif self._ema_backup is not None:
                     for p, b in zip(self._ema_target, self._ema_backup):
                         p.copy_(b)
                     self._ema_backup = None
+                    self.dnn.mark_dirty()
         return res
 
     def eval(self, no_ema=False):
@@ -174,6 +176,10 @@ class VFModel(nn.Module):
     def forward(self, x, t, y):
         """-dnn(cat([x, y], 1), t) (model.py:164-170); x, y complex64 [B,1,F,T] on 'cuda', t float32 [B]."""
         return self.dnn.vf_call(x, t, y, 1)
+
+    def weights_frozen(self):
+        """Context manager of the backbone: no in-place parameter updates inside (see NCSNpp.weights_frozen)."""
+        return self.dnn.weights_frozen()
 
     def euler_sample_(self, x, y, timesteps, stepsizes):
         """Fused N-step Euler loop, in place on x (used by sampling.get_white_box_solver)."""

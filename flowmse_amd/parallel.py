@@ -1,5 +1,8 @@
 """Per-utterance data parallelism: one process per GPU, weights replicated, no collective in the solver loop.
 
+Host-only planning (no GPU, no process group): ``plan_shards`` / ``plan_summary`` -- ``python bench.py --workload vbdmd
+--plan --gpus N`` prints them for BASELINE config[3].
+
 The reference enhances utterances one by one on one GPU (evaluate.py:97); each trajectory depends only on its
 own (Y, z) and the shared read-only weights (sampling/__init__.py:36-60; GroupNorm and attention are
 per-sample), so the path shards by utterance.  The only exchange step is the final gather of the enhanced
@@ -37,6 +40,124 @@ def batches_by_length(indices, lengths, max_batch):
         for k in range(0, len(ids), max_batch):
             out.append((T, ids[k:k + max_batch]))
     return out
+
+
+# Cost model of one sampler call on a batch of b utterances padded to T frames: T * (COST_ALPHA + COST_BETA * b).
+# Fitted to the round-3 MI355X measurements of the N=5 fp32 sampler ([1,1,256,256]: 8.85 k frames/s, [8,1,256,256]:
+# 17.9 k frames/s => 113 us / frame at b = 1, 56 us / frame / utterance at b = 8).  Only RATIOS matter: the planner uses
+# it to decide whether padding a straggler up to a longer batch is cheaper than running it in an under-filled one.
+COST_ALPHA, COST_BETA = 65.0, 48.0
+
+
+def batch_cost(T, b):
+    """Modelled time (us) of one N=5 sampler call on b utterances of T padded frames."""
+    return T * (COST_ALPHA + COST_BETA * b) if b else 0.0
+
+
+def plan_batches(indices, lengths, max_batch, promote=False):
+    """Cost-optimal batching of a set of utterances: [(T, ids)] with T = the batch's padded length (its longest member).
+
+    The utterances are sorted by length (descending); every batch is a run of <= max_batch consecutive ones.  A dynamic
+    programme over the sorted list picks the cut points that minimise the modelled time sum batch_cost(T, b).
+
+    promote=False (default): a batch only holds utterances of ONE padded length, so every utterance runs at exactly the
+    length pad_spec gives it in the reference (util/other.py:83-90) and its result equals the per-utterance path's.
+    promote=True: the stragglers of one length may join the next longer batch, zero-padded up to its T, when the sampler
+    call they save (COST_ALPHA * T') outweighs the frames they add (COST_BETA * (T - T') each).  NOT result-preserving:
+    the network is not padding-invariant (GroupNorm statistics and the attention at the 16-bin level run over all
+    frames of a sample, ncsnpp.py:289-330), so a promoted utterance comes out as the reference would compute it at the
+    LONGER padding -- a valid enhancement of the same input, but not bit-comparable with the reference's own call."""
+    order = sorted(indices, key=lambda i: (-int(lengths[i]), i))
+    n = len(order)
+    best = [0.0] + [float("inf")] * n
+    cut = [0] * (n + 1)
+    for k in range(1, n + 1):
+        for b in range(1, min(max_batch, k) + 1):
+            if not promote and int(lengths[order[k - b]]) != int(lengths[order[k - 1]]):
+                break
+            c = best[k - b] + batch_cost(int(lengths[order[k - b]]), b)
+            if c < best[k] - 1e-9:
+                best[k], cut[k] = c, b
+    out, k = [], n
+    while k > 0:
+        b = cut[k]
+        out.append((int(lengths[order[k - b]]), order[k - b:k]))
+        k -= b
+    out.reverse()
+    return out
+
+
+def _load(batches):
+    return sum(batch_cost(T, len(ids)) for T, ids in batches)
+
+
+def plan_shards(lengths, world_size, max_batch, promote=False):
+    """Deal a ragged utterance set to `world_size` ranks as ready-made batches: [[(T, ids), ...] per rank].
+
+    lengths: padded frame counts (multiples of the model's 64-frame granule).  (1) plan_batches() over the WHOLE set:
+    batches are formed before they are dealt, so a rank receives full batches wherever the set allows it (dealing
+    single utterances first and batching per rank afterwards -- round 3 -- left every rank with one under-filled
+    sampler call per distinct length: at 8 ranks the 512 / 576 / 640-frame buckets ran at batch 1..6 rates).  (2) The
+    batches go, most expensive first, each to the currently least-loaded rank (LPT on modelled time; deterministic).
+    (3) Levelling: while moving part of a batch from the most to the least loaded rank shortens the longer of the
+    two, do so (this is what splits a lone batch over idle ranks when there are fewer batches than ranks)."""
+    batches = plan_batches(range(len(lengths)), lengths, max_batch, promote)
+    batches.sort(key=lambda b: (-batch_cost(b[0], len(b[1])), -b[0], b[1][0]))
+    loads = [0.0] * world_size
+    plan = [[] for _ in range(world_size)]
+    for T, ids in batches:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        plan[r].append((T, list(ids)))
+        loads[r] += batch_cost(T, len(ids))
+    for _ in range(4 * world_size):                                # levelling moves (bounded)
+        hi = max(range(world_size), key=lambda k: (loads[k], -k))
+        lo = min(range(world_size), key=lambda k: (loads[k], k))
+        best = None                                                # (new makespan of the pair, batch index, count moved)
+        for bi, (T, ids) in enumerate(plan[hi]):
+            for m in range(1, len(ids) + 1):                       # move the m SHORTEST members (the tail: ids are
+                moved = ids[len(ids) - m:]                         # sorted long -> short) as a batch of their own
+                Tm = int(lengths[moved[0]])
+                new_hi = loads[hi] - batch_cost(T, len(ids)) + batch_cost(T, len(ids) - m)
+                new_lo = loads[lo] + batch_cost(Tm, m)
+                span = max(new_hi, new_lo)
+                if span < loads[hi] - 1e-6 and (best is None or span < best[0] - 1e-9):
+                    best = (span, bi, m)
+        if best is None:
+            break
+        _, bi, m = best
+        T, ids = plan[hi][bi]
+        moved, kept = ids[len(ids) - m:], ids[:len(ids) - m]
+        if kept:
+            plan[hi][bi] = (T, kept)
+        else:
+            del plan[hi][bi]
+        plan[lo].append((int(lengths[moved[0]]), moved))
+        loads[hi], loads[lo] = _load(plan[hi]), _load(plan[lo])
+    for r in range(world_size):
+        plan[r].sort(key=lambda b: (-b[0], b[1][0]))
+    return plan
+
+
+def plan_summary(plan, lengths, max_batch):
+    """Per-rank figures of a plan_shards() result (host only): utterances, batches, padded frames as dealt (`frames`),
+    frames as run incl. promotion padding (`frames_run`), batch fill = sum(b T) / sum(max_batch T), modelled time."""
+    ranks = []
+    for batches in plan:
+        frames = sum(int(lengths[i]) for _, ids in batches for i in ids)
+        run = sum(T * len(ids) for T, ids in batches)
+        cap = sum(T * max_batch for T, _ in batches)
+        ranks.append({"utterances": sum(len(ids) for _, ids in batches), "batches": len(batches), "frames": frames,
+                      "frames_run": run, "batch_fill": (run / cap) if cap else 1.0,
+                      "promoted": sum(1 for T, ids in batches for i in ids if int(lengths[i]) != T),
+                      "model_ms": sum(batch_cost(T, len(ids)) for T, ids in batches) / 1e3})
+    mean_f = sum(r["frames"] for r in ranks) / max(len(ranks), 1)
+    mean_t = sum(r["model_ms"] for r in ranks) / max(len(ranks), 1)
+    run, cap = sum(r["frames_run"] for r in ranks), sum(T * max_batch for b in plan for T, _ in b)
+    return {"world": len(plan), "max_batch": max_batch, "per_rank": ranks,
+            "frame_imbalance_max_over_mean": (max(r["frames"] for r in ranks) / mean_f) if mean_f else 1.0,
+            "model_time_imbalance_max_over_mean": (max(r["model_ms"] for r in ranks) / mean_t) if mean_t else 1.0,
+            "batch_fill": (run / cap) if cap else 1.0,
+            "promotion_padding_frames": run - sum(r["frames"] for r in ranks)}
 
 
 def _pad_to(t, multiple):
@@ -85,6 +206,7 @@ def gather_spectrograms(local, local_ids, n_total, group=None, pad_multiple=64):
             if i >= 0:
                 buckets.setdefault(_pad_to(t, pad_multiple), [[] for _ in range(world)])[r].append((k, i, t))
     out = [None] * n_total if rank == 0 else None
+    pending = []                                                   # rank 0: (per_rank table, received slabs) per bucket
     for Tp in sorted(buckets, reverse=True):
         per_rank = buckets[Tp]
         kmax = max(len(v) for v in per_rank)
@@ -94,22 +216,44 @@ def gather_spectrograms(local, local_ids, n_total, group=None, pad_multiple=64):
         recv = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
         dist.gather(slab, recv, dst=0, group=group)
         if rank == 0:
-            for r in range(world):
-                got = recv[r].cpu()
-                for row, (_, i, t) in enumerate(per_rank[r]):
-                    out[i] = torch.view_as_complex(got[row, :, :t].contiguous())
+            pending.append((per_rank, recv))
+    if rank == 0:
+        # Device -> host only AFTER the last gather has been enqueued: the copies of one bucket never sit between two
+        # collectives (round 3 copied bucket by bucket, so every RCCL gather waited for the previous bucket's blocking
+        # .cpu()).  On GPUs the rows go into ONE pinned staging buffer with async copies and a single synchronise.
+        rows = [(recv[r], row, i, t) for per_rank, recv in pending for r in range(world)
+                for row, (_, i, t) in enumerate(per_rank[r])]
+        if on_gpu and rows:
+            total = sum(F * t * 2 for _, _, _, t in rows)
+            stage = torch.empty(total, dtype=torch.float32).pin_memory()
+            off = 0
+            views = []
+            for src, row, i, t in rows:
+                v = stage[off:off + F * t * 2].view(F, t, 2)
+                v.copy_(src[row, :, :t], non_blocking=True)
+                views.append((i, v))
+                off += F * t * 2
+            torch.cuda.current_stream().synchronize()
+            for i, v in views:
+                out[i] = torch.view_as_complex(v.clone())
+        else:
+            for src, row, i, t in rows:
+                out[i] = torch.view_as_complex(src[row, :, :t].cpu().contiguous())
     return out
 
 
-def enhance_sharded(sample_fn, specs, max_batch=8, group=None, pad_multiple=64, keep_padding=False, stats=None):
+def enhance_sharded(sample_fn, specs, max_batch=8, group=None, pad_multiple=64, keep_padding=False, stats=None,
+                    promote=False, plan=None):
     """Enhance a ragged set of utterances data-parallel over the ranks of `group` (BASELINE config 4; the reference's
     loop over the test set is evaluate.py:97-136, one utterance per sampler call on one GPU).
 
     specs: list of complex64 spectrograms [F, T_i] (every rank holds the same list, or at least the entries of its
     own shard -- only the LENGTHS of the others are read); sample_fn(Y, ids) -> X maps a zero-padded batch Y [b,1,F,T]
     of equal padded length to the enhanced batch (ids = global utterance indices of the rows, e.g. to pick
-    reproducible noise).  Utterances are dealt to ranks by padded length (LPT), batched by equal padded length,
-    enhanced and gathered to rank 0 with ONE exchange step at the very end (gather_spectrograms).  Returns on rank 0
+    reproducible noise).  The set is cut into equal-length batches first and the batches are dealt to the ranks by
+    modelled time (plan_shards; `plan` = a precomputed plan_shards() result, e.g. one rank's share of a larger world;
+    `promote`: see plan_batches -- off by default because it changes the promoted utterances' results), enhanced and
+    gathered to rank 0 with ONE exchange step at the very end (gather_spectrograms).  Returns on rank 0
     the list of enhanced spectrograms, None elsewhere:
 
     * keep_padding=False: each cropped back to its own [F, T_i] (the spectrogram of the utterance);
@@ -119,22 +263,24 @@ def enhance_sharded(sample_fn, specs, max_batch=8, group=None, pad_multiple=64, 
       waveform.  Use it whenever waveforms must equal the per-utterance path's (``SpecTransform.synthesize``).
 
     stats (optional dict) receives this rank's share of the job: ``utterances``, ``batches``, ``frames`` (sum of the
-    padded frame counts it enhanced), ``true_frames``, ``sample_s`` (wall time of its sampler calls, device drained)
-    and ``gather_s`` (the exchange).  Load imbalance = the spread of ``frames`` / ``sample_s`` over the ranks.
+    padded frame counts it enhanced), ``frames_run`` (the same incl. promotion padding), ``batch_fill`` (frames_run /
+    sum(max_batch * T) over its sampler calls), ``true_frames``, ``sample_s`` (wall time of its sampler calls, device
+    drained) and ``gather_s`` (the exchange).  Load imbalance = the spread of ``frames`` / ``sample_s`` over the ranks.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     true_len = [int(s.shape[-1]) for s in specs]
     padded = [_pad_to(t, pad_multiple) for t in true_len]
-    mine = shard_utterances(padded, world)[rank]
+    batches = plan_shards(padded, world, max_batch, promote)[rank] if plan is None else plan[rank]
+    mine = [i for _, ids in batches for i in ids]
     out_local, ids_local = [], []
     t0 = time.perf_counter()
-    batches = batches_by_length(mine, padded, max_batch)
     for T, ids in batches:
         Y = torch.stack([torch.nn.functional.pad(specs[i], (0, T - true_len[i])) for i in ids])[:, None]
         X = sample_fn(Y.contiguous(), ids)
         for row, i in enumerate(ids):
-            out_local.append(X[row, 0] if keep_padding else X[row, 0, :, :true_len[i]])
+            # keep_padding: the utterance's OWN padded length (what pad_spec gives it), also inside a promoted batch
+            out_local.append(X[row, 0, :, :padded[i]] if keep_padding else X[row, 0, :, :true_len[i]])
             ids_local.append(i)
     if stats is not None:
         if torch.cuda.is_available() and out_local and out_local[0].is_cuda:
@@ -142,7 +288,10 @@ def enhance_sharded(sample_fn, specs, max_batch=8, group=None, pad_multiple=64, 
         t1 = time.perf_counter()
     res = gather_spectrograms(out_local, ids_local, len(specs), group=group, pad_multiple=pad_multiple)
     if stats is not None:
+        run = sum(T * len(ids) for T, ids in batches)
+        cap = sum(T * max_batch for T, _ in batches)
         stats.update(utterances=len(mine), batches=len(batches), frames=sum(padded[i] for i in mine),
+                     frames_run=run, batch_fill=(run / cap) if cap else 1.0,
                      true_frames=sum(true_len[i] for i in mine), sample_s=t1 - t0,
                      gather_s=time.perf_counter() - t1)
     return res

@@ -11,6 +11,8 @@ current stream with no host synchronisation.  Any other callable ``VF_fn`` / reg
 generic plugin loop, exactly like the reference; that loop keeps its time grid on the host, so it never reads a
 device tensor back either.
 """
+import contextlib
+
 import torch
 
 from .odesolvers import ODEsolver, ODEsolverRegistry
@@ -27,13 +29,32 @@ def time_grid(T_rev, t_eps, N, device="cpu"):
     return timesteps, torch.stack(steps)
 
 
+def _frozen(VF_fn):
+    """``VF_fn.weights_frozen()`` when the field is a HIP-backed model (its per-call weight-version scan then runs once
+    per sampler loop instead of once per network evaluation), else a no-op context."""
+    f = getattr(VF_fn, "weights_frozen", None)
+    return f() if callable(f) else contextlib.nullcontext()
+
+
+def _fused_tableau(odesolver_cls):
+    """Name of the library's fused implementation of this solver class, or None (plugin loop).
+
+    Only a class that opts in ITSELF qualifies: ``fused_tableau`` must be set in the class's own ``__dict__`` and its
+    ``update_fn`` must be the one defined next to it.  A plugin that subclasses a built-in solver
+    (``class My(EulerODEsolver)``) and overrides ``update_fn`` inherits the attribute but not the claim -- it goes
+    through the generic loop, where its ``update_fn`` is what runs."""
+    name = odesolver_cls.__dict__.get("fused_tableau")
+    if name is None or "update_fn" not in odesolver_cls.__dict__:
+        return None
+    return name
+
+
 def get_white_box_solver(odesolver_name, ode, VF_fn, Y, Y_prior=None, T_rev=1.0, t_eps=0.03, N=30, z=None,
                          **kwargs):
     """Returns ``ode_solver() -> (x_result, N)``.  Extra keyword ``z``: explicit prior noise (reproducibility)."""
     odesolver_cls = ODEsolverRegistry.get_by_name(odesolver_name)
     odesolver = odesolver_cls(ode, VF_fn)
-    fused = (getattr(odesolver_cls, "fused_tableau", None) is not None and hasattr(VF_fn, "rk_sample_")
-             and Y.is_cuda)
+    fused = _fused_tableau(odesolver_cls) is not None and hasattr(VF_fn, "rk_sample_") and Y.is_cuda
 
     def ode_solver(Y_prior=Y_prior):
         with torch.no_grad():
@@ -48,17 +69,19 @@ def get_white_box_solver(odesolver_name, ode, VF_fn, Y, Y_prior=None, T_rev=1.0,
             timesteps, stepsizes = time_grid(T_rev, t_eps, N)
             if fused:
                 xt = VF_fn.rk_sample_(xt.contiguous(), Y.contiguous(), timesteps.tolist(), stepsizes.tolist(),
-                                      odesolver_cls.fused_tableau)
+                                      _fused_tableau(odesolver_cls))
                 return xt, N
             try:
-                for i in range(N):
-                    # t and the step size stay host values (0-d CPU tensors): `ones(B) * t` is a fill kernel with a
-                    # scalar argument, and a solver may inspect the step ("does it land on t = 0?") with no readback
-                    t = timesteps[i]
-                    stepsize = stepsizes[i]
-                    vec_t = torch.ones(Y.shape[0], device=Y.device) * float(t)
-                    odesolver.step_start_time = float(t)
-                    xt = odesolver.update_fn(xt, vec_t, Y, stepsize)
+                with _frozen(VF_fn):
+                    for i in range(N):
+                        # t and the step size stay host values (0-d CPU tensors): `ones(B) * t` is a fill kernel with
+                        # a scalar argument, and a solver may inspect the step ("does it land on t = 0?") with no
+                        # readback
+                        t = timesteps[i]
+                        stepsize = stepsizes[i]
+                        vec_t = torch.ones(Y.shape[0], device=Y.device) * float(t)
+                        odesolver.step_start_time = float(t)
+                        xt = odesolver.update_fn(xt, vec_t, Y, stepsize)
             finally:
                 odesolver.step_start_time = None
             return xt, N
@@ -93,8 +116,9 @@ def get_black_box_solver(ode, VF_fn, y, rtol=1e-5, atol=1e-5, T_rev=1.0, t_eps=0
                 vec_t = torch.ones(y.shape[0], device=xt.device) * t
                 return to_flattened_numpy(VF_fn(xt, vec_t, y))
 
-            solution = integrate.solve_ivp(ode_func, (T_rev, t_eps), to_flattened_numpy(x), rtol=rtol, atol=atol,
-                                           method=method, **solver_kwargs)
+            with _frozen(VF_fn):
+                solution = integrate.solve_ivp(ode_func, (T_rev, t_eps), to_flattened_numpy(x), rtol=rtol, atol=atol,
+                                               method=method, **solver_kwargs)
             x = torch.tensor(solution.y[:, -1]).reshape(y.shape).to(device).type(torch.complex64)
             return x, solution.nfev
 

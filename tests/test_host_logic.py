@@ -179,6 +179,81 @@ def test_shard_utterances_balance():
     assert all(len(ids) <= 2 and all(lengths[i] == T for i in ids) for T, ids in b)
 
 
+def test_plan_shards_config3_partition():
+    """BASELINE config[3]'s stand-in set dealt to 2 / 4 / 8 ranks (host only): every utterance exactly once, batches of one
+    padded length (no promotion by default: results stay those of the per-utterance path), balanced modelled time, and
+    well-filled batches -- the numbers DESIGN section 6 quotes and `bench.py --workload vbdmd --plan` prints."""
+    import bench
+    from flowmse_amd.parallel import plan_batches, plan_shards, plan_summary, shard_utterances, batches_by_length, batch_cost
+    true_len = bench.vbdmd_lengths(bench.VBDMD_UTTS)
+    padded = [((t + 63) // 64) * 64 for t in true_len]
+    ideal = sum(p * (65.0 / 8 + 48.0) for p in padded) / 1e3
+    for world in (1, 2, 4, 8):
+        plan = plan_shards(padded, world, 8)
+        assert sorted(i for b in plan for _, ids in b for i in ids) == list(range(len(padded)))
+        assert all(len(ids) <= 8 and all(padded[i] == T for i in ids) for b in plan for T, ids in b)
+        s = plan_summary(plan, padded, 8)
+        assert s["promotion_padding_frames"] == 0
+        assert s["model_time_imbalance_max_over_mean"] <= 1.01, s
+        assert s["frame_imbalance_max_over_mean"] <= 1.01, s
+        assert s["batch_fill"] >= 0.9, s
+        # within 1.5 % of the all-batches-full bound, and never worse than round 3's deal-utterances-then-batch scheme
+        makespan = max(r["model_ms"] for r in s["per_rank"])
+        assert makespan <= 1.015 * ideal / world, (world, makespan, ideal / world)
+        old = max(sum(batch_cost(T, len(ids)) for T, ids in batches_by_length(m, padded, 8)) / 1e3
+                  for m in shard_utterances(padded, world))
+        assert makespan <= old + 1e-6, (world, makespan, old)
+    # degenerate sets: fewer batches than ranks get split, empty ranks are fine
+    assert plan_shards([], 3, 8) == [[], [], []]
+    assert plan_shards([64], 3, 8) == [[(64, [0])], [], []]
+    two = plan_shards([128, 128, 128], 2, 8)
+    assert sorted(len(ids) for b in two for _, ids in b) == [1, 2]
+    # promotion (opt-in) only ever pads upwards and only merges when the cost model says so
+    pr = plan_batches(range(4), [640, 128, 128, 64], 8, promote=True)
+    assert all(max(([640, 128, 128, 64][i]) for i in ids) == T for T, ids in pr)
+    assert (640, [0]) in pr                                  # 512 frames of padding per member: never worth it
+    assert plan_batches(range(3), [192, 128, 128], 8, promote=True) == [(192, [0, 1, 2])]
+    assert plan_batches(range(3), [192, 128, 128], 8) == [(192, [0]), (128, [1, 2])]
+
+
+def test_fused_sampler_only_for_classes_that_opt_in_themselves():
+    """A plugin that subclasses a built-in solver and overrides update_fn must go through the plugin loop (its update_fn
+    is what runs); only the built-in classes themselves map to the library's fused loop."""
+    from flowmse_amd.sampling import ODEsolverRegistry, _fused_tableau, get_white_box_solver
+    from flowmse_amd.sampling.odesolvers import EulerODEsolver, HeunODEsolver, RK4ODEsolver
+    from flowmse_amd.odes import FLOWMATCHING
+    assert (_fused_tableau(EulerODEsolver), _fused_tableau(HeunODEsolver), _fused_tableau(RK4ODEsolver)) == \
+        ("euler", "heun", "rk4")
+
+    class Doubling(EulerODEsolver):
+        calls = 0
+
+        def update_fn(self, x, t, y, stepsize, *args):
+            type(self).calls += 1
+            return x * 2
+
+    class Inheriting(RK4ODEsolver):
+        pass
+
+    assert _fused_tableau(Doubling) is None and _fused_tableau(Inheriting) is None
+    name = "_doubling_test"
+    ODEsolverRegistry.register(name)(Doubling)
+    try:
+
+        class Field:                                  # looks like a HIP-backed model: has rk_sample_
+            def rk_sample_(self, *a):
+                raise AssertionError("fused loop taken for a subclass with its own update_fn")
+
+            def __call__(self, x, t, y):
+                return x
+
+        y = torch.ones(1, 1, 4, 64, dtype=torch.complex64)
+        x, n = get_white_box_solver(name, FLOWMATCHING(), Field(), y, N=3, z=torch.zeros_like(y))()
+        assert Doubling.calls == 3 and n == 3 and torch.allclose(x, y * 8)
+    finally:
+        ODEsolverRegistry._registry.pop(name, None)
+
+
 def test_spec_transform_roundtrip():
     from flowmse_amd.data_module import SpecTransform
     st = SpecTransform()
