@@ -481,16 +481,14 @@ def main():
                                    "own passes, 2*FETCH_SIZE + WRITE_SIZE)")
             form = None
             if args.precision == "fp32" and not os.environ.get("FLOWSE_NO_WINOGRAD"):
-                form = "F(2,3)" if os.environ.get("FLOWSE_WINOGRAD") == "f23" else "F(4,3)"
-            f43_name = ("flowse::conv3x3_f43_kernel<2, false, 1>" if os.environ.get("FLOWSE_F43_BN64")
-                        else "flowse::conv3x3_f43_kernel<2, false, 2>")
-            kname = ({"F(4,3)": f43_name, "F(2,3)": "flowse::conv3x3_wino_kernel<2>"}[form] +
+                form = "F(4,3)"
+            kname = ("flowse::conv3x3_f43_kernel<2, false, 2>" +
                      f" (fp32 {form}-Winograd implicit-GEMM 3x3 conv, 8x16 pixel x 128 channel block, LDS halo, fused "
                      "GroupNorm+SiLU input, weights streamed from L2 in MFMA fragment order)" if form else
                      "flowse::conv3x3_halo_kernel<2,2,2,2,2> (fp32 implicit-GEMM 3x3 conv, 128x128 tile, LDS halo, "
                      "fused GroupNorm+SiLU input)" if args.precision == "fp32" else
                      "flowse::conv3x3_halo16_kernel / conv3x3_halo_bf16_kernel (16-bit operand LDS-halo 3x3 kernels)")
-            issue = {"F(4,3)": 0.5, "F(2,3)": 2.0 / 3.0, None: 3.0 if args.precision == "bf16x3" else 1.0}[form]
+            issue = {"F(4,3)": 0.5, None: 3.0 if args.precision == "bf16x3" else 1.0}[form]
             issued = ach * issue
             peak = PEAK_FP32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_16BIT_MATRIX_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": kname,

@@ -231,21 +231,10 @@ struct ConvArgs {
     // tile to `partial` [ksplit][B*H*W][Cout]; splitk_reduce sums the slices and applies the epilogue.
     int ksplit = 1;
     float* partial = nullptr;
-    // In-launch reduction (optional): `sk_ticket` = one zero-initialised counter per output tile (gridDim.x of them).
-    // Every slice stores its raw tile, then takes a ticket; the slice that takes the LAST one sums all slices in slice
-    // order (the result does not depend on the arrival order) and runs the epilogue -- no splitk_reduce launch.  The
-    // counter is reset by that block, so the buffer serves every launch on the stream.  `sk_group` = flat pixels per
-    // statistics block (conv_splitk_stats_group) or 0 for one statistics block per 8 x 16 pixel tile (F(4,3) slices).
-    unsigned* sk_ticket = nullptr;
-    int sk_group = 0;
-    // Second partial set folded into the same reduction (two-pass form only): the split-K slices of ANOTHER convolution
+    // Second partial set folded into the same reduction: the split-K slices of ANOTHER convolution
     // with the same output shape -- the 1x1 shortcut Conv_2(x) of a ResnetBlock, whose sum with Conv_1(h) is the block's
     // output (layerspp.py:268-274) -- are added slice by slice after this conv's own, plus that conv's bias `bias_x`.
     // Saves the shortcut's own reduction launch and the round trip of its output through HBM.
-    // F(4,3) kernel: walk the pixel tiles last-to-first (FLOWSE_F43_SNAKE=1 alternates the direction from one launch to
-    // the next so that a conv starts with the part of its input its predecessor wrote last; measured: no effect -- the
-    // 268 MB activations of the 256 x 256 level do not survive in the 256 MB Infinity Cache either way).  A-B hook.
-    int reverse = 0;
     const float* partial2 = nullptr;    // [ksplit2][B*H*W][Cout]
     int ksplit2 = 0;
     const float* bias_x = nullptr;      // [Cout] or null
@@ -265,11 +254,9 @@ struct ConvArgs {
     const void* wq = nullptr;
     int terms = 0;
     int wq_f16 = 0;     // 1: the planes hold IEEE half instead of bf16 (terms must be 1; BASELINE config 5)
-    // optional Winograd weights of a 3x3 conv in MFMA fragment order (launch_wino_weights / launch_f43_weights):
-    // when set and the shape qualifies (conv_supports_wino) the fp32 halo kernel runs its Winograd variant,
-    // F(2,3) (wino_f43 = 0, 12 transformed taps per channel pair) or F(4,3) (wino_f43 = 1, 18 taps)
+    // optional F(4,3) Winograd weights of a 3x3 conv in MFMA fragment order (launch_f43_weights): when set and the
+    // shape qualifies (conv_supports_wino) the fp32 3x3 runs the Winograd kernel (18 transformed taps per channel pair)
     const float* wino = nullptr;
-    int wino_f43 = 0;
     // activation storage types (DT_*).  16-bit inputs are taken by the 16-bit matrix-core kernels (halo 3x3 with
     // Cout % 128 == 0, flat 1x1 / small 3x3: `wq` = the [Cout][taps][Cin] weights in the matching 16-bit type, terms = 1)
     // and by the 4-channel heads; 16-bit outputs by those plus the 4-channel input convs, the fp32 flat kernel
@@ -285,15 +272,12 @@ bool conv16_uses_halo(int B, int H, int W, int C1, int C2, int Cout, int taps);
 int conv16_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps);
 // elementwise storage conversion (n elements, n % 4 == 0)
 int launch_convert(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, hipStream_t s);
-// Winograd weight transforms along the kernel's vertical axis, packed [Cout][9][Cin] -> fragment order, on device
-int launch_wino_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s);
+// F(4,3) Winograd weight transform along the kernel's vertical axis, packed [Cout][9][Cin] -> fragment order, on device
 int launch_f43_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s);
-inline int64_t conv_wino_numel(int Cout, int Cin) { return (int64_t)Cout * 18 * Cin; }   // room for either form
-bool conv_wino_default_f43();       // FLOWSE_WINOGRAD=f23 selects the F(2,3) kernel for the model handle
+inline int64_t conv_wino_numel(int Cout, int Cin) { return (int64_t)Cout * 18 * Cin; }
 bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // whole-K F(4,3) launches of this shape use 128-channel blocks (conv3x3_f43_kernel<GN, false, 2>)
 bool conv_f43_wide(int B, int H, int W, int Cout);
-bool conv_f43_forced_bn64();      // FLOWSE_F43_BN64=1: the 64-channel form everywhere (A-B hook)
 // host helper: split fp32 conv weights [Cout][Cin][3][3] into the packed bf16 planes described above
 void pack_conv_bf16(const float* w, int Cout, int Cin, int terms, uint16_t* dst, bool f16 = false);
 inline int64_t conv_bf16_numel(int Cout, int Cin, int terms) { return (int64_t)Cout * 9 * Cin * (terms == 1 ? 1 : 2); }
@@ -320,11 +304,9 @@ int launch_splitk_reduce_gn(const ConvArgs& a, const float* gamma, const float* 
                             float* gn_mean, float* gn_scale, hipStream_t s);
 // number of K slices launch_conv will use for this shape (1 = no split) and the partial-buffer size in floats
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps);
-// split-K launches reduce inside the launch (ConvArgs::sk_ticket) when FLOWSE_SPLITK_IN_LAUNCH=1 (slower, measured)
-bool conv_splitk_in_launch();
 // flat pixels per statistics block of a split-K conv's output
 int conv_splitk_stats_group(int HW);
-// true when this 3x3 shape runs as slices of the F(4,3) kernel (statistics then come per 8 x 16 tile when reduced in-launch)
+// true when this 3x3 shape runs as slices of the F(4,3) kernel
 bool conv_splitk_is_wino(int B, int H, int W, int Cin, int Cout, int taps);
 // true when the 4-channel input conv runs on the matrix cores (then it also emits fused GroupNorm statistics,
 // H*W/128 partial blocks per sample)

@@ -41,7 +41,7 @@ extern "C" {
 #define FLOWSE_ERR_STATE 3
 #define FLOWSE_ERR_SHAPE 4
 
-#define FLOWSE_ABI_VERSION 2
+#define FLOWSE_ABI_VERSION 3
 #define FLOWSE_MAX_LEVELS 8
 #define FLOWSE_MAX_ATTN 4
 
@@ -108,8 +108,8 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
  * 0 (default): every operand, product and accumulation is fp32 (v_mfma_f32_32x32x2_f32), activations fp32.  3x3
  *   convolutions with Cin % 32 == 0 and Cout % 64 == 0 on images the LDS-halo kernel covers are evaluated in the F(4,3)
  *   Winograd form along the filter's vertical axis (half the multiplies; transformed fp32 operands, rounding error ~3x
- *   the direct sum's, 4e-7..2e-6 rel-L2 per layer); FLOWSE_WINOGRAD=f23 selects the F(2,3) form, FLOWSE_NO_WINOGRAD=1
- *   the direct form, whose result is bit for bit an fmaf chain.
+ *   the direct sum's, 4e-7..2e-6 rel-L2 per layer); FLOWSE_NO_WINOGRAD=1 selects the direct form, whose result is bit
+ *   for bit an fmaf chain.
  * 1 "bf16x3": fp32 activations; the operands of the big 3x3 convs are split x = hi + lo in bf16 and the products
  *   hi*hi + hi*lo + lo*hi accumulated in fp32 (fp32-class accuracy, ~1e-5 end to end).
  * 2 "bf16" (BASELINE config 3) / 3 "fp16" (BASELINE config 5): 16-bit STORAGE modes -- every wide activation tensor
@@ -154,7 +154,8 @@ int flowse_euler_sample(flowse_model* m, void* x_inout, const void* y, const flo
  * network evaluations per step) or _RK4 (classical, 4 per step).  A step that ends at t = 0 -- the last step of the
  * reference's grid -- is taken as the reference's Euler update: the field divides by t (ncsnpp.py:398) and embeds
  * log t, so no stage is ever evaluated at t <= 0.  Stages are chained through the head kernel (next stage input and
- * slope accumulation fused into it): no extra launches, no host synchronisation, each evaluation one hipGraph launch. */
+ * slope accumulation fused into it): no extra launches, no host synchronisation; each evaluation is the shape's launch
+ * list issued as plain launches (default) or, under FLOWSE_GRAPH=1, one hipGraph launch. */
 #define FLOWSE_TABLEAU_EULER 0
 #define FLOWSE_TABLEAU_HEUN 1
 #define FLOWSE_TABLEAU_RK4 2
@@ -229,23 +230,17 @@ int flowse_op_conv3x3_gn(const float* in1, int C1, const float* in2, int C2, con
                          float eps, int silu, const float* w, const float* bias, const float* bias2,
                          int bias2_stride, const float* res, float* out, int B, int H, int W, int Cout, float scale,
                          float* scratch, void* stream);
-/* The same fused ResnetBlock half computed with a Winograd form of the 3x3 filter along its vertical axis --
- * F(2,3): 4 multiplies per output pair instead of 6 (2/3 of the direct-convolution FLOPs on the matrix cores);
- * F(4,3): 6 multiplies per four outputs instead of 12 (1/2 of them; fp32 error ~3x the direct sum's) -- the kernels
- * the model handle uses for every 3x3 convolution with Cout % 64 == 0 on images large enough for the halo kernel
- * (F(4,3) by default, FLOWSE_WINOGRAD=f23 selects F(2,3), FLOWSE_NO_WINOGRAD=1 the direct kernel).
- * gamma == NULL: plain convolution without the GroupNorm + SiLU input stage.  `w` is the packed [Cout][9][Cin]
- * weight as for flowse_op_conv2d; the transformed weights are derived into `scratch`
- * (flowse_op_conv3x3_f23_scratch_floats floats, enough for either form).  Other shapes: FLOWSE_ERR_SHAPE. */
-int flowse_op_conv3x3_f23(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
-                          float eps, int silu, const float* w, const float* bias, const float* bias2,
-                          int bias2_stride, const float* res, float* out, int B, int H, int W, int Cout, float scale,
-                          float* scratch, void* stream);
+/* The same fused ResnetBlock half computed with the F(4,3) Winograd form of the 3x3 filter along its vertical axis: 6
+ * multiplies per four outputs instead of 12 (half of the direct-convolution FLOPs on the matrix cores; fp32 error ~3x the
+ * direct sum's) -- the kernel the model handle uses for every 3x3 convolution with Cout % 64 == 0 on images large enough
+ * for the halo tiling (FLOWSE_NO_WINOGRAD=1 selects the direct kernel).  gamma == NULL: plain convolution without the
+ * GroupNorm + SiLU input stage.  `w` is the packed [Cout][9][Cin] weight as for flowse_op_conv2d; the transformed
+ * weights are derived into `scratch` (flowse_op_conv3x3_f43_scratch_floats floats).  Other shapes: FLOWSE_ERR_SHAPE. */
 int flowse_op_conv3x3_f43(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
                           float eps, int silu, const float* w, const float* bias, const float* bias2,
                           int bias2_stride, const float* res, float* out, int B, int H, int W, int Cout, float scale,
                           float* scratch, void* stream);
-int64_t flowse_op_conv3x3_f23_scratch_floats(int B, int H, int W, int C, int Cout);
+int64_t flowse_op_conv3x3_f43_scratch_floats(int B, int H, int W, int C, int Cout);
 /* GroupNorm(min(C/4,32) groups, eps) [+ SiLU] over cat[in1,in2] (layerspp.py:219,231; ncsnpp.py:337).
  * `scratch` must hold flowse_op_group_norm_scratch_floats(B,H*W,C1+C2) floats. */
 int64_t flowse_op_group_norm_scratch_floats(int B, int HW, int C);

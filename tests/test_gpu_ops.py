@@ -155,11 +155,11 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("form", ["f23", "f43"])
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_conv3x3_winograd(G, case, form):
-    """F(2,3) Winograd form of the halo kernel (with and without the fused GroupNorm + SiLU input stage) against
-    the plain fp32 direct convolution; also against the direct HIP kernel on the same input."""
+def test_conv3x3_winograd(G, case):
+    """F(4,3) Winograd kernel (with and without the fused GroupNorm + SiLU input stage) against the plain fp64 direct
+    convolution; also against the direct HIP kernel on the same input."""
+    form = "f43"
     B, H, W, C1, C2, Cout, has_b2, has_res, scale, silu = case
     Cc = C1 + C2
     x1 = rnd(41, (B, C1, H, W)) * 1.5 + 0.3
@@ -183,27 +183,26 @@ def test_conv3x3_winograd(G, case, form):
         return t * scale
 
     ref = finish(F.conv2d(hn.double(), w.double(), bias.double(), padding=1).float())
-    got = G.conv3x3_f23(x1, w, g, be, bias, x2, bias2, res, scale, silu, form=form)
+    got = G.conv3x3_f43(x1, w, g, be, bias, x2, bias2, res, scale, silu)
     err = C.rel_l2(got, ref)
     direct = C.rel_l2(G.conv3x3_gn(x1, g, be, w, bias, x2, bias2, res, scale, silu), ref)
     print(f"winograd {form} rel-L2 {err:.2e}   direct kernel {direct:.2e}")
     assert err < TOL
     # plain conv (no normalisation), unnormalised input with a DC offset: the row differences d0 - d2 cancel it
     ref0 = finish(F.conv2d(xin.double(), w.double(), bias.double(), padding=1).float())
-    got0 = G.conv3x3_f23(x1, w, None, None, bias, x2, bias2, res, scale, form=form)
+    got0 = G.conv3x3_f43(x1, w, None, None, bias, x2, bias2, res, scale)
     assert C.rel_l2(got0, ref0) < TOL
 
 
 def test_conv3x3_winograd_rejects_uncovered_shapes(G):
-    """The Winograd entry points refuse shapes their tiling does not cover (status SHAPE + message) instead of
+    """The Winograd entry point refuses shapes its tiling does not cover (status SHAPE + message) instead of
     silently running another kernel: small image, Cout not a multiple of 64, H not a multiple of 8."""
     from flowmse_amd._lib import FlowseError
     for (B, Cc, H, W, Cout) in ((1, 64, 32, 32, 64), (2, 64, 128, 128, 96), (2, 64, 100, 128, 64)):
         x = rnd(61, (B, Cc, H, W))
         w = rnd(62, (Cout, Cc, 3, 3), 0.05)
-        for form in ("f23", "f43"):
-            with pytest.raises(FlowseError, match="not covered"):
-                G.conv3x3_f23(x, w, form=form)
+        with pytest.raises(FlowseError, match="not covered"):
+            G.conv3x3_f43(x, w)
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 16, 8), (1, 128, 32, 32), (2, 16, 8, 8), (1, 512, 4, 4),

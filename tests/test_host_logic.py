@@ -21,7 +21,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(_lib.lib, name), f"{name} declared in flowse_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.lib.flowse_abi_version() == 2
+    assert _lib.lib.flowse_abi_version() == 3
     assert _lib.lib.flowse_device_count() >= 0
 
 

@@ -31,7 +31,7 @@ if __name__ == "__main__":
         res = torch.randn(B, H, W, Cout, generator=g).cuda()
         gam, bet = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
         out = torch.empty(B, H, W, Cout, device="cuda")
-        scratch = torch.empty(L.flowse_op_conv3x3_f23_scratch_floats(B, H, W, C, Cout), device="cuda")
+        scratch = torch.empty(L.flowse_op_conv3x3_f43_scratch_floats(B, H, W, C, Cout), device="cuda")
         st = _lib.current_stream()
 
         def call():
