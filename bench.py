@@ -100,7 +100,7 @@ def cpu_baseline(sd, nsolver, frames, reps, budget_s=60.0, oracle_utt=None):
     if oracle_utt is not None:          # the checker's own N-step answer for ONE utterance of the timed batch (parity echo)
         y = torch.from_numpy(synth.synth_spectrogram(oracle_utt, 1, 256, frames))
         z = torch.from_numpy(synth.synth_noise(oracle_utt, 1, 256, frames))
-        x_oracle = S.euler_sample_net(sd, cfg, y, z, N=nsolver)
+        x_oracle = S.euler_sample_net(sd, cfg, y, z, N=nsolver)[0]
     return x_oracle, {"value": frames / (nsolver * t_nfe), "unit": "frames/s", "cores": best_n, "kind": "port",
             "host_logical_cpus": logical, "cgroup_cpu_quota": quota,
             "thread_sweep_s_per_nfe_at_64_frames": sweep,

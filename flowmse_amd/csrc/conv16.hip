@@ -2,9 +2,9 @@
 // bf16x3 (split operands, fp32 storage), bf16 and fp16 (BASELINE configs 2 / 4: 16-bit activation storage).
 // Replaces (reference) the same ops as the fp32 kernels: ddpm_conv3x3 / ddpm_conv1x1
 // (flowmse/backbones/ncsnpp_utils/layers.py:100-124) inside ResnetBlockBigGANpp (layerspp.py:245-274).
-//   conv3x3_halo_bf16_kernel   LDS-halo 3x3, per-tap weight tile, two blocks per CU: bf16x3 and small 16-bit launches
-//   conv3x3_halo16_kernel      LDS-halo 3x3 built for the 16-bit storage modes (8x16 / 16x16 pixel tile x 128 channels, output
-//                              straight from the accumulators)
+//   conv3x3_halo_bf16_kernel   LDS-halo 3x3, per-tap weight tile, two blocks per CU: bf16x3 and the 16-bit launches too small
+//                              for the producer / consumer kernel of conv16_pc.hip (which takes everything from 64 x 64 up
+//                              at batch 8)
 //   conv_flat16_kernel         flat 1x1 / small 3x3 on 16-bit activations, split-K with fp32 slabs
 //   convert_kernel             storage conversion at the boundaries; pack_conv_bf16: host-side operand planes
 #include "conv_common.h"
@@ -259,299 +259,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
     }
 #undef FLOWSE_STEP16
     conv_epilogue<2, 2, 2, 2, OT>(a, acc, smem, m_tl, n0, M, HW, 0, W);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Single-plane (bf16 / half) LDS-halo 3x3 kernel, built for THREE blocks per CU.
-//
-// Same tile (8 x 16 pixels x 128 output channels, 4 waves x 2 x 2 tiles of v_mfma_f32_32x32x16) and the same halo staging
-// with fused GroupNorm + SiLU as conv3x3_halo_bf16_kernel.  A 16-bit MFMA phase is 16x shorter than an fp32 one, so with
-// K = 9 x 128 .. 9 x 512 the kernel is a chain of short latencies -- LDS fragment reads, one barrier per tap, the
-// epilogue (which for K = 1152 costs about as many issue cycles as the whole main loop) -- and what hides them is
-// occupancy: measured (rocprofv3 SQ counters) the two-blocks-per-CU form kept the matrix pipe 28 % busy with the waves
-// parked on s_waitcnt / s_barrier 36 % of the time, no matter whether one or three taps were staged per barrier.  So:
-//   * LDS <= 43 KB: one tap's weight tile (10 KB) double-buffered + the halo (15 KB); the epilogue handles the 128
-//     output channels as two halves of 64 through a 35 KB C tile;
-//   * <= 168 VGPRs: one weight register set, requested one tap ahead (pinned in front of the MFMAs: hipcc otherwise
-//     sinks the loads behind them and exposes the full L2 latency every tap).
-// IT / OT: storage types of the inputs and of res / out (float, or the 16-bit type of the operands).
-// MT = 8 x 16 pixel sub-tiles per block, stacked vertically: 1 (three blocks per CU) or 2 (a 16 x 16 pixel tile, two
-// blocks per CU, 16-bit inputs only).  With MT = 2 every staged weight tile feeds twice the MFMAs: half the per-block
-// weight stream from L2, half the barriers and B-fragment reads per MFMA, a smaller halo overhead (324 / 256 vs 180 / 128
-// pixels read per pixel computed).
-template <bool GN, bool F16, class IT, class OT, int MT = 1>
-__global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv3x3_halo16_kernel(ConvArgs a) {
-    constexpr int BN = 128, ROWB = 80, TROWS = 8 * MT, HROWS = (TROWS + 2) * 18, H_LOADS = (HROWS * 8 + 255) / 256;
-    constexpr int HPITCH = 18 * ROWB + 96;                 // halo image row: 1536 B = 0 mod 256, so the two image rows a
-                                                           // wave's 32 lanes touch use the same bank pattern (conflict-free)
-    constexpr int BTILE = BN * ROWB;                       // one tap's weight tile
-    constexpr unsigned ES = sizeof(IT);
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* Hs = reinterpret_cast<char*>(smem);              // [TROWS + 2][HPITCH]
-    char* Bs = Hs + (TROWS + 2) * HPITCH;                           // [2 buffers][BN][ROWB]
-
-    const int tid = threadIdx.x;
-    const int H = a.H, W = a.W, HW = H * W;
-    const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
-    const int nchunks = Cin / KC;
-    const int n_ntiles = a.Cout / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
-    const int tiles_x = W >> 4, tiles_img = tiles_x * (H / TROWS);
-    const int b = mt / tiles_img, tt = mt - b * tiles_img;
-    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
-    const int y0 = ty * TROWS, x0 = tx * 16, n0 = nt * BN;
-    const int m_tl = (b * H + y0) * W + x0;
-
-    const int col4 = tid & 7, row0 = tid >> 3;             // halo staging: 8 channel quads x 32 rows per pass
-    // Window row / column of this thread's halo quads, two quads per register (hy | hx << 8 in 16 bits each): the pixel
-    // offset (hy W + hx) and the LDS offset are re-derived where used, once per chunk -- registers matter more here.
-    unsigned hyx[(H_LOADS + 1) / 2];
-    unsigned hin = 0;                                      // bit q: quad q lies inside the image
-    unsigned hval = 0;                                     // bit q: quad q is a halo pixel at all (hr < HROWS)
-#pragma unroll
-    for (int q = 0; q < H_LOADS; ++q) {
-        const int hr = row0 + 32 * q;
-        const int hy = hr / 18, hx = hr - hy * 18;
-        const bool in = hr < HROWS && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
-        const unsigned pk = (unsigned)hy | ((unsigned)hx << 8);
-        if (q & 1) hyx[q >> 1] |= pk << 16; else hyx[q >> 1] = pk;
-        hin |= in ? (1u << q) : 0u;
-        hval |= hr < HROWS ? (1u << q) : 0u;
-    }
-    // `fence_hyx()` makes the packed coordinates opaque at the point of use: without it hipcc hoists every derived
-    // per-quad offset out of the chunk loop and, out of registers, parks them in scratch (reloaded under vmcnt(0)).
-    auto fence_hyx = [&]() {
-#pragma unroll
-        for (int k = 0; k < (H_LOADS + 1) / 2; ++k) asm volatile("" : "+v"(hyx[k]));
-    };
-    auto h_y = [&](int q) { return (hyx[q >> 1] >> ((q & 1) * 16)) & 0xffu; };
-    auto h_x = [&](int q) { return (hyx[q >> 1] >> ((q & 1) * 16 + 8)) & 0xffu; };
-    const int bcol = tid & 3, brow0 = tid >> 2;            // weight staging: 4 x 16-byte columns, rows brow0 + 64 q
-    const unsigned bvo0 = (unsigned)((n0 + brow0) * 9 * nchunks * 64 + bcol * 16), bvo_step = (unsigned)(64 * 9 * nchunks * 64);
-    const int64_t wbase = (int64_t)m_tl - W - 1;
-    const int wpix = (TROWS + 1) * W + 18;
-    const IT* in1p = reinterpret_cast<const IT*>(a.in1);
-    const IT* in2p = reinterpret_cast<const IT*>(a.in2);
-    const IT* win1 = in1p + wbase * C1;                   // window origins of the two inputs (block-uniform)
-    const IT* win2 = C2 ? in2p + wbase * C2 : in1p;
-    const __amdgpu_buffer_rsrc_t rsrcw =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wq), 0, a.Cout * 9 * nchunks * 64, 0x00020000);
-
-    typename RawQuad<IT>::type rh[H_LOADS];                // raw until transformed; afterwards .xy = the quad as 4 x 16 bit
-    u32x4 rb[2];
-    float4 g_mu, g_sc, g_be;
-    auto gloadH = [&](int chunk) {
-        const int c0 = chunk * KC;
-        const bool second = c0 >= C1;                      // block-uniform: the descriptor is built from scalars, per chunk
-        const unsigned soff = (unsigned)(second ? c0 - C1 : c0) * ES;
-        const unsigned cs = (unsigned)(second ? C2 : C1);
-        // the window origin goes through readfirstlane: under SGPR pressure hipcc otherwise keeps it in VGPRs and wraps
-        // every load in a waterfall loop
-        const uint64_t wsel = reinterpret_cast<uint64_t>(second ? win2 : win1);
-        const uint64_t wuni = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wsel) |
-                              ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wsel >> 32)) << 32);
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<IT*>(wuni), 0, __builtin_amdgcn_readfirstlane(wpix * (int)cs * (int)ES), 0x00020000);
-        unsigned hin_l = hin;
-        asm volatile("" : "+v"(hin_l));                    // opaque, like the coordinates: no hoisted per-quad masks
-        fence_hyx();
-#pragma unroll
-        for (int q = 0; q < H_LOADS; ++q) {
-            const unsigned pix = h_y(q) * (unsigned)W + h_x(q);
-            const unsigned off = ((hin_l >> q) & 1u) ? (pix * cs + (unsigned)col4 * 4u) * ES : OOB;
-            rh[q] = buf_ld_raw<IT>(rsrc, off, soff);
-        }
-        if (GN) {
-            const int cg = c0 + col4 * 4;
-            g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
-            g_sc = *reinterpret_cast<const float4*>(a.gn.scale + (int64_t)b * Cin + cg);
-            g_be = *reinterpret_cast<const float4*>(a.gn.beta + cg);
-        }
-    };
-    // GroupNorm + SiLU of quad Q in fp32 (packed forms, v_exp / v_rcp), then one rounding to the operand type:
-    // rh[Q].xy = the quad as 4 x 16 bit.  Out-of-image pixels are zero AFTER the activation.
-    auto xform1 = [&](int Q) {
-        u32x4 t = widen_quad<IT>(rh[Q]);
-        if (GN) t = a.gn_silu ? gn_quad<2>(t, g_mu, g_sc, g_be, (hin >> Q) & 1u) : gn_quad<1>(t, g_mu, g_sc, g_be, (hin >> Q) & 1u);
-        const float v[4] = {__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
-        unsigned short h[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (F16) {
-                const _Float16 c = (_Float16)v[e];
-                h[e] = __builtin_bit_cast(unsigned short, c);
-            } else {
-                const __bf16 c = (__bf16)v[e];
-                h[e] = __builtin_bit_cast(unsigned short, c);
-            }
-        }
-        rh[Q].x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-        rh[Q].y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-    };
-    auto lstoreH = [&]() {
-        fence_hyx();
-#pragma unroll
-        for (int q = 0; q < H_LOADS; ++q)
-            if ((hval >> q) & 1u)
-                *reinterpret_cast<uint2*>(Hs + h_y(q) * HPITCH + h_x(q) * ROWB + col4 * 8) = make_uint2(rh[q].x, rh[q].y);
-    };
-    const int S_all = nchunks * 9;
-    auto gloadB = [&](int s) {
-        const int chunk = s / 9, tap = s - chunk * 9;
-        const unsigned soff_b = (unsigned)((tap * nchunks + chunk) * 64);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo0 + q * bvo_step, soff_b, 0);
-    };
-    auto lstoreB = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            *reinterpret_cast<u32x4*>(Bs + buf * BTILE + (brow0 + 64 * q) * ROWB + bcol * 16) = rb[q];
-    };
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 31, kh = lane >> 5;
-    int abase[2];                                          // sub-tile 0; sub-tile t adds 8 t image rows
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int py = 2 * (wm * 2 + i) + (li >> 4), px = li & 15;
-        abase[i] = (py + 1) * HPITCH + (px + 1) * ROWB + kh * 16;
-    }
-    f32x16 acc[MT][2][2];
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
-
-    gloadH(0);
-    gloadB(0);
-#pragma unroll
-    for (int q = 0; q < H_LOADS; ++q) xform1(q);
-    lstoreH();
-    lstoreB(0);
-    __syncthreads();
-
-    // One tap.  TAP is a literal: the nine taps of a chunk are straight-line code, no load sits under a branch.  The
-    // next tap's weights are requested first (pinned in front of the MFMAs), the next chunk's halo at tap 1; its six
-    // quads are normalised one per tap behind the MFMAs of taps 2..7 and written after tap 8's barrier.
-#define FLOWSE_TAP16(TAP)                                                                                            \
-    {                                                                                                                \
-        constexpr int tap = TAP;                                                                                     \
-        const int s = chunk * 9 + tap;                                                                               \
-        const int buf = s & 1;                                                                                       \
-        gloadB(min(s + 1, S_all - 1));                                                                               \
-        if (tap == 1) gloadH(min(chunk + 1, nchunks - 1));                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        constexpr int tapoff = (tap / 3 - 1) * HPITCH + (tap % 3 - 1) * ROWB;                                        \
-        const char* Bb = Bs + buf * BTILE + (wn * 64 + li) * ROWB + kh * 16;                                         \
-        _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) {                                                           \
-            bf16x8 af[MT][2], bf[2];                                                                                 \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
-                _Pragma("unroll") for (int t = 0; t < MT; ++t)                                                       \
-                    af[t][i] = *reinterpret_cast<const bf16x8*>(Hs + abase[i] + t * 8 * HPITCH + tapoff + mh * 32);  \
-                bf[i] = *reinterpret_cast<const bf16x8*>(Bb + i * 32 * ROWB + mh * 32);                              \
-            }                                                                                                        \
-            _Pragma("unroll") for (int t = 0; t < MT; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i)             \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
-                if (F16)                                                                                             \
-                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[t][i]),       \
-                                                                         __builtin_bit_cast(f16x8, bf[j]), acc[t][i][j], 0, 0, 0); \
-                else                                                                                                 \
-                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][i], bf[j], acc[t][i][j], 0, 0, 0);  \
-            }                                                                                                        \
-        }                                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        /* GroupNorm of the next chunk's quads, in the shadow of the MFMAs just issued: taps 2..7 take them all */   \
-        if (tap >= 2 && tap <= 7) {                                                                                  \
-            constexpr int QPT = (H_LOADS + 5) / 6;                                                                   \
-            _Pragma("unroll") for (int qq = 0; qq < QPT; ++qq)                                                       \
-                if ((tap - 2) * QPT + qq < H_LOADS) xform1((tap - 2) * QPT + qq);                                    \
-        }                                                                                                            \
-        lstoreB(buf ^ 1);                                /* at the very last tap: a spare tile into the idle buffer */ \
-        __syncthreads();                                                                                             \
-        if (tap == 8) {                                  /* everyone is done with this chunk's halo */              \
-            lstoreH();                                                                                               \
-            __syncthreads();                                                                                         \
-        }                                                                                                            \
-    }
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        FLOWSE_TAP16(0) FLOWSE_TAP16(1) FLOWSE_TAP16(2) FLOWSE_TAP16(3) FLOWSE_TAP16(4)
-        FLOWSE_TAP16(5) FLOWSE_TAP16(6) FLOWSE_TAP16(7) FLOWSE_TAP16(8)
-    }
-#undef FLOWSE_TAP16
-
-    if constexpr (sizeof(OT) == 2) {
-        // ---- 16-bit storage: output straight from the accumulators (halo16_out_direct)
-        const int bsmp = m_tl / HW;
-        const int rem = m_tl - bsmp * HW;
-        const int tile0 = ((rem / W) >> 3) * (W >> 4) + ((rem % W) >> 4);                  // 8 x 16 statistics tiles, row-major
-        halo16_out_direct<OT, MT>(a, acc, smem, m_tl, W, n0, bsmp, tile0, W >> 4);
-    } else {
-    // ---- epilogue in two halves of 64 output channels (C tile [128][68] floats = 35 KB instead of 68 KB).  Half h is
-    // held by the waves with wn == h; then all 256 threads run the shared output stage on it.
-        constexpr int CROW = 68;
-        float* Cs = smem;
-        float* red = smem + 128 * CROW;
-        const int bsmp = m_tl / HW;
-        const int rem = m_tl - bsmp * HW;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const int tile = (((rem / W) >> 3) + t) * (W >> 4) + ((rem % W) >> 4);     // 8 x 16 statistics tiles, row-major
-#pragma unroll 1
-            for (int half = 0; half < 2; ++half) {
-                __syncthreads();                           // previous users of the tile (main loop / earlier pass) are done
-                if (wn == half) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                                Cs[row * CROW + jn * 32 + li] = acc[t][i][jn][r];
-                            }
-                }
-                __syncthreads();
-                tile128x64_out<OT>(a, Cs, CROW, red, m_tl + t * 8 * W, W, n0 + half * 64, bsmp, tile);
-            }
-        }
-    }
-}
-
-template <bool F16>
-static int launch_halo16(const ConvArgs& a, hipStream_t s) {
-    using T16 = typename std::conditional<F16, f16_t, bf16_t>::type;
-    const int64_t M = (int64_t)a.B * a.H * a.W;
-    if (a.in_dt != a.out_dt || (a.in_dt != DT_F32 && a.in_dt != St<T16>::dt) || a.terms != 1 || a.partial) {
-        set_error("halo16: input / output storage must agree and match the operand type; no split-K form");
-        return ERR_ARG;
-    }
-    // 16 x 16 pixel tiles (two sub-tiles per block) when the input is 16-bit, H allows it and >= 512 blocks remain
-    const bool mt2 = a.in_dt != DT_F32 && (a.H & 15) == 0 && (M / 256) * (a.Cout / 128) >= 512;
-    const int grid = (int)(M / (mt2 ? 256 : 128)) * (a.Cout / 128);
-    const size_t lds_stage = (size_t)(mt2 ? 18 : 10) * (18 * 80 + 96) + (size_t)2 * 128 * 80;
-    const size_t lds_epi = ((size_t)128 * 68 + 4 * 64 * 2) * sizeof(float);
-    size_t lds = (a.in_dt == DT_F32 && lds_epi > lds_stage) ? lds_epi : lds_stage;      // the staged epilogue is the fp32-storage one
-#define FLOWSE_LH16(GNF, IT, OT, MTV)                                                                             \
-    {                                                                                                             \
-        if (const int rc = allow_lds<&conv3x3_halo16_kernel<GNF, F16, IT, OT, MTV>>(lds)) return rc;              \
-        hipLaunchKernelGGL((conv3x3_halo16_kernel<GNF, F16, IT, OT, MTV>), dim3(grid), dim3(256), lds, s, a);     \
-    }
-    if (a.in_dt == DT_F32) {
-        if (a.gn.mean) FLOWSE_LH16(true, float, float, 1) else FLOWSE_LH16(false, float, float, 1)
-    } else if (mt2) {
-        if (a.gn.mean) FLOWSE_LH16(true, T16, T16, 2) else FLOWSE_LH16(false, T16, T16, 2)
-    } else {
-        if (a.gn.mean) FLOWSE_LH16(true, T16, T16, 1) else FLOWSE_LH16(false, T16, T16, 1)
-    }
-#undef FLOWSE_LH16
-    FLOWSE_LAUNCH_CHECK();
-    return OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -883,12 +590,10 @@ static int launch_halo_bf16(const ConvArgs& a, hipStream_t s) {
 
 int launch_halo_bf16x3(const ConvArgs& a, hipStream_t s) { return launch_halo_bf16<3>(a, s); }
 
-// 16-bit operands (terms = 1), fp32 or 16-bit storage: the three-blocks-per-CU / 16 x 16-tile kernel wins once there are
-// >= 1024 blocks (>= 4 / 3 rounds of 768); smaller grids keep the two-blocks-per-CU per-tap form
+// 16-bit operands (terms = 1), fp32 or 16-bit storage, on launches the producer / consumer kernel (conv16_pc.hip) does not
+// take: fewer than 256 of its items, H not a multiple of 16, fp32 storage (FLOWSE_FP32_STORAGE=1)
 int launch_halo16_any(const ConvArgs& a, hipStream_t s) {
-    const int64_t blocks = ((int64_t)a.B * a.H * a.W / 128) * (a.Cout / 128);
-    if (blocks < 1024) return a.wq_f16 ? launch_halo_bf16<1, true>(a, s) : launch_halo_bf16<1>(a, s);
-    return a.wq_f16 ? launch_halo16<true>(a, s) : launch_halo16<false>(a, s);
+    return a.wq_f16 ? launch_halo_bf16<1, true>(a, s) : launch_halo_bf16<1>(a, s);
 }
 
 }  // namespace flowse

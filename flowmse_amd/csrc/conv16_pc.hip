@@ -1,0 +1,636 @@
+// Producer / consumer LDS-halo 3x3 convolution for the 16-bit storage modes (bf16 / fp16 activations, BASELINE configs
+// 2 and 4): Conv_k(act(GroupNorm_k(x))) of ResnetBlockBigGANpp (flowmse/backbones/ncsnpp_utils/layerspp.py:246-249,
+// 265-267 = ddpm_conv3x3, layers.py:118-124, behind nn.GroupNorm + SiLU), concat input of ncsnpp.py:337, temb bias
+// (layerspp.py:262-263), skip (x + h)/sqrt(2) (:271-274) and the next GroupNorm's partial statistics.
+//
+// Structure (ONE persistent block per CU, eight waves, tiles of 16 x 16 pixels x 128 output channels dealt to the blocks in
+// XCD-contiguous ranges):
+//   * Waves 0-3 ("consumers", one per SIMD) only read MFMA fragments from LDS and issue MFMAs: 16 per (tap, 32-channel
+//     chunk) step and wave in two halves of 16 channels, the fragments of the next half requested before the MFMAs of the
+//     current one.  They never wait for memory and carry no VALU work in the main loop.
+//   * Waves 4-7 ("producers", one per SIMD) run ahead on the SAME stream of steps: raw halo pieces (16 bytes = 8 channels of
+//     a pixel) are requested a whole chunk before they are needed, weight tiles eleven steps ahead (a ring of nine register
+//     sets) and written to LDS two steps ahead.  Their global loads stay in flight across the block barrier (plain loads, no
+//     LDS-DMA: __syncthreads() then only waits for LDS traffic).
+//   * One barrier per step.  In interval s consumers READ weight slots s % 3 and (s + 1) % 3 and producers WRITE slot
+//     (s + 2) % 3.
+//   * GroupNorm + SiLU of a chunk's halo (affine folded to one FMA per element, v_exp / v_rcp, one rounding to the operand
+//     type) runs as ONE burst per chunk at a barrier pair (T) during which the consumers issue nothing; the burst for a
+//     tile's first chunk runs under the previous tile's output stage.
+//   * Output stage in the consumers (pc16_out_wide): 16-byte residual loads / stores through wave-private LDS transposition
+//     tiles, GroupNorm partial statistics of the tensor written; its block barrier (S) is the tile hand-over point.
+// LDS: 2 halo buffers [18][18 px x 80 B + 96] (32 KB apart) + 3 weight slots [128][80 B] + statistics scratch + the output
+// stage's four transposition tiles = 133 KB.
+//
+// Measured (round 4, tools/pc16_ts.py = s_memtime accumulators per role, [8,.,256,256] 128 -> 128 with residual, cycles per
+// tile; ideal MFMA time 36 steps x 512 = 18.4 k): fragments + MFMA issue 20 k, step barriers 6 k, halo bursts 10 k, output
+// stage 9.5 k -> ~46 k without the probes = 0.40 of the MFMA roof on this shape, the same speed as the all-waves-equal kernel it
+// replaces (conv3x3_halo16_kernel, rounds 2-3: 16 x 16 tile, two blocks per CU), which is why this is a replacement, not a gain:
+//   - VALU work of one wave and MFMA work of another wave on the SAME SIMD do not overlap: spread under the MFMAs, one piece
+//     per step, the GroupNorm + SiLU of a chunk stretched the nine steps by 2 500-3 000 cycles; as one burst with the matrix
+//     pipe idle it takes 2 900 -- 412 cycles per 16-byte piece = 16 transcendentals x 16 cycles + 39 other VALU x 4: the
+//     cost is the instruction time itself (v_exp / v_rcp are quarter rate), not arbitration (s_setprio on either role moves
+//     time between the two accumulators, sum unchanged), not instruction order (stage-by-stage over 24 channel pairs: 2 900
+//     vs 3 300), not the in-order return of HBM loads ahead of weight tiles (a three- vs nine-deep weight ring: no change).
+//   - dword stores from the accumulator layout are store-issue bound (~7 B / cycle / CU: 10 k cycles per tile, 18 k with
+//     the residual loads); 16-byte accesses through the transposition tiles: 8.4 k / 9.5 k.
+// So on gfx950 the floor of this fused op is MFMA time + transform time + output stage ~ 18.4 + 10 + >= 5 k cycles per tile
+// (~0.55 of the roof); what is left above it here: step barriers (6 k) and LDS-write-bound transposition in the output stage.
+#include "conv_common.h"
+#ifdef FLOWSE_MEASURE
+#include "pc_measure.h"
+#else
+#define PC_TS_DECL
+#define PC_TS_START
+#define PC_TS_ADD(K)
+#define PC_TS_FLUSH(BASE)
+#endif
+
+namespace flowse {
+
+namespace {
+constexpr int PC_ROWB = 80;                        // bytes per halo pixel / weight row: 32 x 16 bit + 16 pad (conflict-free b128 reads)
+constexpr int PC_HPITCH = 18 * PC_ROWB + 96;       // halo image row: 1536 B = 0 mod 256
+constexpr int PC_HBUF_X = 32768;                   // pitch of the two halo buffers (18 rows = 27 KB each; a power of two: the offset toggles by XOR)
+constexpr int PC_WSLOT = 128 * PC_ROWB;            // one tap's weight tile (128 output channels x 32 channels)
+constexpr int PC_RED = 2 * 2 * 128 * 2 * 4;        // statistics scratch of the output stage: [2 waves][2 sub-tiles][128 ch][mean, M2]
+constexpr int PC_TSCR = 4 * 32 * 68 * 4;             // the consumers' transposition tiles (pc16_out_wide)
+constexpr int PC_LDS = 2 * PC_HBUF_X + 3 * PC_WSLOT + PC_RED + PC_TSCR;
+constexpr int PC_PIECES = 6;                       // 16-byte halo pieces per producer thread and chunk (324 x 4 / 256)
+
+// position of one (tile, channel block) work item
+struct PcItem {
+    int b, y0, x0, n0;
+};
+}  // namespace
+
+// ---- output stage of one consumer wave: its 4 x (32 pixels x 64 channels) of accumulators (sub-tile t, row pair i, both
+// channel tiles j) leave through a WAVE-PRIVATE fp32 LDS tile [32 px][64 ch] so that every global access is 16 bytes -- a
+// lane ends up with 8 consecutive channels of one pixel: one dwordx4 residual load and one dwordx4 store per 8 values
+// instead of a dword each.  (halo16_out_direct's dword stores are store-issue bound at ~7 B / cycle / CU: 10 k cycles per
+// 16 x 16 x 128 tile, 18 k with the residual loads, measured with tools/pc16_ts.py -- as long as the 36-step main loop.)
+// LDS traffic per lane and tile: 128 ds_write_b32 + 32 ds_read_b128, in-order per wave: no barrier.  Bias / per-sample
+// bias / residual / scale, ONE rounding to the storage type, and the GroupNorm partial statistics (mean, M2 per
+// channel and 8 x 16 statistics tile) of exactly what was stored: per lane over its 8 pixels of a sub-tile (pivoted),
+// equal-count Chan merges over the 8 lanes that share a channel octet (64 pixels), then with the wave that holds the
+// other 64 pixels through `red` ([2][2][128][2] floats) after ONE block barrier -- which the producers match.
+// two fp32 -> one dword of two 16-bit values, round to nearest even.  bf16: ONE v_cvt_pk_bf16_f32 (hipcc lowers two
+// scalar __bf16 casts to two conversions plus a v_bitop3 merge -- 12 instead of 4 instructions per staged halo piece, and
+// every producer instruction costs 7-10 cycles next to the consumers' MFMA stream, tools/pc16_ts.py)
+template <bool F16>
+__device__ __forceinline__ unsigned pc_pack2(float a, float b) {
+    if constexpr (F16) {
+        return St<f16_t>::pack2(a, b);
+    } else {
+        unsigned r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+}
+
+constexpr int PCW_PITCH = 68;                              // floats per pixel row of the transposition tile (64 + 16 B)
+template <class OT>
+__device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2][2][2], float* T, float* red, int b, int y0,
+                                              int x0, int n0, int tiles_x) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kh = lane >> 5;
+    const int o = lane & 7, pl = lane >> 3;                // read side: channel octet, pixel lane (pixels pl + 8 k)
+    const int H = a.H, W = a.W, Cout = a.Cout;
+    const int ch0 = n0 + wn * 64 + o * 8;                  // this lane's 8 output channels
+    const OT* resp = reinterpret_cast<const OT*>(a.res);
+    OT* outp = reinterpret_cast<OT*>(a.out);
+    const bool has_res = resp != nullptr;
+    float bq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bq[e] = a.bias ? a.bias[ch0 + e] : 0.f;
+    if (a.bias2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bq[e] += a.bias2[(int64_t)b * a.bias2_stride + ch0 + e];
+    }
+    const float scale = a.scale;
+    // element offset of pixel (pl + 8 k) of row pair (t, i): row = y0 + 8 t + 2 (2 wm + i) + (p >> 4), p = pl + 8 k
+    auto pix_off = [&](int t, int i, int k) {
+        const int p = pl + 8 * k;
+        const int row = y0 + 8 * t + 2 * (2 * wm + i) + (p >> 4), col = x0 + (p & 15);
+        return ((int64_t)(b * H + row) * W + col) * Cout + ch0;
+    };
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v rres[4];
+    auto load_res = [&](int t, int i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rres[k] = *reinterpret_cast<const u32x4v*>(resp + pix_off(t, i, k));
+    };
+    if (has_res) load_res(0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float piv[8], s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { piv[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // accumulators -> T[pixel][channel]: register r of tile j = pixel (r & 3) + 8 (r >> 2) + 4 kh, channel 32 j + li
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kh) * PCW_PITCH + j * 32 + li] = acc[t][i][j][r];
+            u32x4v cur[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[k] = rres[k];
+            if (has_res && !(t == 1 && i == 1)) load_res(i == 1 ? t + 1 : t, i ^ 1);     // next row pair's residual in flight
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 lo = *reinterpret_cast<const float4*>(T + (pl + 8 * k) * PCW_PITCH + o * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(T + (pl + 8 * k) * PCW_PITCH + o * 8 + 4);
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const unsigned rw[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+                unsigned w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = v[2 * q] + bq[2 * q], v1 = v[2 * q + 1] + bq[2 * q + 1];
+                    if (has_res) {
+                        float r0, r1;
+                        St<OT>::unpack2(rw[q], r0, r1);
+                        v0 += r0;
+                        v1 += r1;
+                    }
+                    v0 *= scale;
+                    v1 *= scale;
+                    w[q] = St<OT>::pack2(v0, v1);
+                    St<OT>::unpack2(w[q], v0, v1);                         // statistics of what is stored
+                    if (i == 0 && k == 0) { piv[2 * q] = v0; piv[2 * q + 1] = v1; }
+                    const float d0 = v0 - piv[2 * q], d1 = v1 - piv[2 * q + 1];
+                    s1[2 * q] += d0; s2[2 * q] = fmaf(d0, d0, s2[2 * q]);
+                    s1[2 * q + 1] += d1; s2[2 * q + 1] = fmaf(d1, d1, s2[2 * q + 1]);
+                }
+                *reinterpret_cast<u32x4v*>(outp + pix_off(t, i, k)) = u32x4v{w[0], w[1], w[2], w[3]};
+            }
+        }
+        if (!a.stats) continue;
+        // 8 values per lane and channel -> the 8 pixel lanes of the octet (64 = this wave's pixels of sub-tile t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float mean = piv[e] + s1[e] * 0.125f;
+            float m2 = fmaxf(s2[e] - s1[e] * s1[e] * 0.125f, 0.f);
+            float cnt = 8.f;
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                const float mo = __shfl_xor(mean, off), qo = __shfl_xor(m2, off);
+                const float d = mo - mean;
+                m2 = m2 + qo + d * d * (0.5f * cnt);
+                mean = 0.5f * (mean + mo);
+                cnt *= 2.f;
+            }
+            if (pl == 0) {
+                float* dst = red + (((wm * 2 + t) * 128) + wn * 64 + o * 8 + e) * 2;
+                dst[0] = mean;
+                dst[1] = m2;
+            }
+        }
+    }
+    __syncthreads();                                       // (S) always: the producers' hand-over point as well
+    if (!a.stats) return;
+    if (tid < 128) {
+        const int tile0 = (y0 >> 3) * tiles_x + (x0 >> 4);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float ma = red[((0 * 2 + t) * 128 + tid) * 2], qa = red[((0 * 2 + t) * 128 + tid) * 2 + 1];
+            const float mb = red[((1 * 2 + t) * 128 + tid) * 2], qb = red[((1 * 2 + t) * 128 + tid) * 2 + 1];
+            const float d = mb - ma;
+            float* dst = a.stats + (((int64_t)b * a.stats_nblk + tile0 + t * tiles_x) * Cout + n0 + tid) * 2;
+            dst[0] = 0.5f * (ma + mb);
+            dst[1] = qa + qb + d * d * 32.f;
+        }
+    }
+}
+
+template <int GN, bool F16>
+__global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
+    using T16 = typename std::conditional<F16, f16_t, bf16_t>::type;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Hs = reinterpret_cast<char*>(smem);              // [2][18][PC_HPITCH] at a pitch of PC_HBUF_X
+    char* Ws = Hs + 2 * PC_HBUF_X;                         // [3][128][PC_ROWB]
+    float* red = reinterpret_cast<float*>(Ws + 3 * PC_WSLOT);
+    float* tscr = red + PC_RED / 4;                        // [4 consumer waves][32][PCW_PITCH]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W;
+    const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
+    const int nchunks = Cin / KC;
+    const int n_ntiles = a.Cout >> 7;
+    const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 4);
+    // ---- this block's items: XCD x (= blockIdx & 7, where the dispatcher puts the block) walks the contiguous item range
+    // [I x / 8, I (x + 1) / 8) with its gridDim / 8 blocks interleaved, so neighbouring tiles (shared halo rows, the same
+    // weights) run at the same time behind one L2.  Placement is a speed matter only.
+    const int I = a.B * tiles_img * n_ntiles;
+    const int G8 = (int)gridDim.x >> 3;
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int i_lo = (int)((int64_t)I * xcd / 8), i_hi = (int)((int64_t)I * (xcd + 1) / 8);
+    const int first = i_lo + slot;
+    if (first >= i_hi) return;                             // (whole block: nobody reaches a barrier)
+    const int n_items = (i_hi - first + G8 - 1) / G8;
+    const int Ctot = n_items * nchunks;                    // chunks in this block's stream
+    auto item_at = [&](int k) {                            // k-th item of this block
+        const int it = first + k * G8;
+        const int mt = it / n_ntiles, nt = it - mt * n_ntiles;
+        PcItem p;
+        p.b = mt / tiles_img;
+        const int tt = mt - p.b * tiles_img;
+        const int ty = tt / tiles_x;
+        p.y0 = ty * 16;
+        p.x0 = (tt - ty * tiles_x) * 16;
+        p.n0 = nt * 128;
+        return p;
+    };
+
+    if (wave < 4) {
+        // =============================================================================== consumers: fragments + MFMA
+        const int lane = tid & 63;
+        const int wm = wave >> 1, wn = wave & 1;
+        const int li = lane & 31, kh = lane >> 5;
+        int abase[2];                                      // sub-tile 0; sub-tile t adds 8 image rows
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int py = 2 * (wm * 2 + i) + (li >> 4), px = li & 15;
+            abase[i] = (py + 1) * PC_HPITCH + (px + 1) * PC_ROWB + kh * 16;
+        }
+        const int bbase = (wn * 64 + li) * PC_ROWB + kh * 16;
+        f32x16 acc[2][2][2];
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+        };
+        zero_acc();
+        // A step = two half-steps of 16 channels (mh = 0, 1), 8 MFMAs each.  The fragments of half-step h + 1 are requested
+        // before the MFMAs of half-step h: two sets of 6 fragments (48 registers), not two whole steps' worth.
+        bf16x8 xa[2][2], xb[2], ya[2][2], yb[2];             // [t][i], [j]
+
+        // fragments of half-step (halo buffer offset HOFF, weight slot SL, tap TAP, half MH) into set (FA, FB)
+#define FLOWSE_PC_LOADF(FA, FB, HOFF, SL, TAP, MH)                                                                   \
+    {                                                                                                                \
+        constexpr int tapoff = ((TAP) / 3 - 1) * PC_HPITCH + ((TAP) % 3 - 1) * PC_ROWB + (MH) * 32;                  \
+        const char* Hb = Hs + (HOFF) + tapoff;                                                                       \
+        const char* Wb = Ws + (SL) * PC_WSLOT + bbase + (MH) * 32;                                                   \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i)                  \
+            FA[t][i] = *reinterpret_cast<const bf16x8*>(Hb + abase[i] + t * 8 * PC_HPITCH);                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+            FB[j] = *reinterpret_cast<const bf16x8*>(Wb + j * 32 * PC_ROWB);                                         \
+    }
+#define FLOWSE_PC_MMA(FA, FB)                                                                                        \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i)                      \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+        if (F16)                                                                                                     \
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, FA[t][i]),               \
+                                                                 __builtin_bit_cast(f16x8, FB[j]), acc[t][i][j], 0, 0, 0); \
+        else                                                                                                         \
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[t][i], FB[j], acc[t][i][j], 0, 0, 0);          \
+    }
+        int cit = 0;                                       // chunk inside the current tile
+        int kitem = 0;                                     // ordinal of the current item
+        // One step at tap TAP of the current chunk (halo buffer offset hoff, weight slot TAP % 3).  Entering, set X holds
+        // the fragments of (TAP, mh 0); leaving, those of the next step's mh 0.
+#define FLOWSE_PC_STEP(TAP)                                                                                          \
+    {                                                                                                                \
+        FLOWSE_PC_LOADF(ya, yb, hoff, (TAP) % 3, (TAP), 1)                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        FLOWSE_PC_MMA(xa, xb)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if constexpr ((TAP) < 8) {                                                                                   \
+            FLOWSE_PC_LOADF(xa, xb, hoff, ((TAP) + 1) % 3, ((TAP) + 1) % 9, 0)                                       \
+        } else if (!tile_end) {                            /* (a tile's first fragments: after its halo burst) */  \
+            FLOWSE_PC_LOADF(xa, xb, hoff ^ PC_HBUF_X, 0, 0, 0)                                                       \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        FLOWSE_PC_MMA(ya, yb)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        PC_TS_ADD(0)                                       /* 0: fragments + MFMA issue */                          \
+        __syncthreads();                                                                                             \
+        PC_TS_ADD(1)                                       /* 1: step barrier */                                    \
+    }
+        PC_TS_DECL
+        PC_TS_START
+        __syncthreads();                                   // (A) halo of chunk 0 and the weight tiles of steps 0, 1 are in LDS
+        PC_TS_ADD(2)                                       // 2: prologue wait
+        int hoff = 0;                                      // byte offset of the current chunk's halo buffer: 0 / PC_HBUF_X
+        FLOWSE_PC_LOADF(xa, xb, hoff, 0, 0, 0)
+        for (int gc = 0; gc < Ctot; ++gc) {
+            const bool tile_end = cit == nchunks - 1;
+            if (!tile_end) {                               // (T) the producers normalise the next chunk's halo in one burst while
+                __syncthreads();                           //     no MFMA is in flight on their SIMDs (see the header)
+                PC_TS_ADD(4)                               // 4: waiting for the halo burst
+            }
+            FLOWSE_PC_STEP(0) FLOWSE_PC_STEP(1) FLOWSE_PC_STEP(2) FLOWSE_PC_STEP(3) FLOWSE_PC_STEP(4)
+            FLOWSE_PC_STEP(5) FLOWSE_PC_STEP(6) FLOWSE_PC_STEP(7) FLOWSE_PC_STEP(8)
+            hoff ^= PC_HBUF_X;
+            ++cit;
+            if (tile_end) {                                // the tile is complete: output stage, next tile
+                const PcItem p = item_at(kitem);
+                // (its block barrier (S) is also where the producers hand over the next tile's first halo)
+                pc16_out_wide<T16>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x);
+                zero_acc();
+                cit = 0;
+                ++kitem;
+                PC_TS_ADD(3)                               // 3: output stage
+                if (gc + 1 < Ctot) { FLOWSE_PC_LOADF(xa, xb, hoff, 0, 0, 0) }
+            }
+        }
+        if (wave == 0) { PC_TS_FLUSH(0) }                  // slots 0-7 of the block
+#undef FLOWSE_PC_STEP
+#undef FLOWSE_PC_MMA
+#undef FLOWSE_PC_LOADF
+        return;
+    }
+
+    // =================================================================================== producers: staging
+    const int ltid = tid - 256;
+    const int octet = ltid & 3;                            // this thread's 8-channel group inside a 32-channel chunk
+    const int hp0 = ltid >> 2;                             // halo pixels hp0 + 64 q
+    // Window coordinates of the thread's pieces, packed (hy | hx << 8) two per register, made opaque where used so that
+    // nothing derived from them is hoisted into long-lived registers.
+    unsigned hyx[PC_PIECES / 2];
+#pragma unroll
+    for (int q = 0; q < PC_PIECES; ++q) {
+        const int hp = hp0 + 64 * q;
+        const int hy = hp / 18, hx = hp - hy * 18;
+        const unsigned pk = (unsigned)hy | ((unsigned)hx << 8);
+        if (q & 1) hyx[q >> 1] |= pk << 16; else hyx[q >> 1] = pk;
+    }
+    const bool last_valid = hp0 + 64 * (PC_PIECES - 1) < 324;      // piece 5 exists for 16 threads only
+    int hlds[PC_PIECES];                                   // LDS byte offset of each piece inside a halo buffer (plain registers:
+#pragma unroll                                             // the kernel's allocation is set by the consumers, the producers have room)
+    for (int q = 0; q < PC_PIECES; ++q) {
+        const int hp = hp0 + 64 * q;
+        const int hy = hp / 18, hx = hp - hy * 18;
+        hlds[q] = hy * PC_HPITCH + hx * PC_ROWB + octet * 16;
+    }
+    auto h_y = [&](int q) { return (hyx[q >> 1] >> ((q & 1) * 16)) & 0xffu; };
+    auto h_x = [&](int q) { return (hyx[q >> 1] >> ((q & 1) * 16 + 8)) & 0xffu; };
+    const int bcol = ltid & 3, brow0 = ltid >> 2;          // weight staging: 16-byte column, rows brow0 + 64 q
+    const unsigned bvo0 = (unsigned)(brow0 * 9 * Cin * 2 + bcol * 16), bvo_step = (unsigned)(64 * 9 * Cin * 2);
+    const __amdgpu_buffer_rsrc_t rsrcw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wq), 0, a.Cout * 9 * Cin * 2, 0x00020000);
+    const T16* in1p = reinterpret_cast<const T16*>(a.in1);
+    const T16* in2p = reinterpret_cast<const T16*>(a.in2);
+    const int wpix = 17 * W + 18;
+
+    // stream cursor: (item, chunk) of global chunk index g, clamped to the stream's last chunk (a redundant reload at the
+    // very end keeps every load unconditional)
+    struct Cur {
+        PcItem p;
+        int chunk;
+    };
+    auto cursor = [&](int g) {
+        g = min(g, Ctot - 1);
+        const int k = g / nchunks;
+        Cur c;
+        c.p = item_at(k);
+        c.chunk = g - k * nchunks;
+        return c;
+    };
+    // raw halo pieces of chunk `c` (8 consecutive channels of a pixel per piece; out-of-image pixels read 0)
+    u32x4 ra[PC_PIECES], rb[PC_PIECES];                    // two chunks in flight
+    unsigned hin_a = 0, hin_b = 0;                         // in-image bits of the pieces held in ra / rb
+    f32x2 sca[4], sha[4], scb[4], shb[4];                  // folded GroupNorm affine y = x sc + sh per channel pair, two chunks' worth
+#define FLOWSE_PC_HLOAD(R, HIN, CURV)                                                                                \
+    {                                                                                                                \
+        const Cur& cc = (CURV);                                                                                      \
+        const int c0 = cc.chunk * KC;                                                                                \
+        const bool second = c0 >= C1;                                                                                \
+        const unsigned cs = (unsigned)(second ? C2 : C1);                                                            \
+        const int64_t wbase = ((int64_t)cc.p.b * H + cc.p.y0 - 1) * W + cc.p.x0 - 1;                                 \
+        const uint64_t wsel = reinterpret_cast<uint64_t>((second ? in2p : in1p) + wbase * (int64_t)cs);              \
+        const uint64_t wuni = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wsel) |              \
+                              ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wsel >> 32)) << 32); \
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(                                       \
+            reinterpret_cast<T16*>(wuni), 0, __builtin_amdgcn_readfirstlane(wpix * (int)cs * 2), 0x00020000);        \
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((second ? c0 - C1 : c0) * 2);                 \
+        unsigned hin = 0;                                                                                            \
+        _Pragma("unroll") for (int k = 0; k < PC_PIECES / 2; ++k) asm volatile("" : "+v"(hyx[k]));                   \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
+            const unsigned hy = h_y(q), hx = h_x(q);                                                                 \
+            const bool in = (q < PC_PIECES - 1 || last_valid) && (unsigned)(cc.p.y0 - 1 + (int)hy) < (unsigned)H &&  \
+                            (unsigned)(cc.p.x0 - 1 + (int)hx) < (unsigned)W;                                         \
+            hin |= in ? (1u << q) : 0u;                                                                              \
+            const unsigned off = in ? ((hy * (unsigned)W + hx) * cs + (unsigned)octet * 8u) * 2u : OOB;              \
+            R[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, soff, 0);                                        \
+        }                                                                                                            \
+        HIN = hin;                                                                                                   \
+    }
+    // GroupNorm parameters of the chunk at `cc`, folded: y = (x - mean) scale + beta = x scale + (beta - mean scale)
+    auto load_params = [&](const Cur& cc, f32x2 (&scv)[4], f32x2 (&shv)[4]) {
+        if (!GN) return;
+        const int cg = cc.chunk * KC + octet * 8;
+        const float* mp = a.gn.mean + (int64_t)cc.p.b * Cin + cg;
+        const float* sp = a.gn.scale + (int64_t)cc.p.b * Cin + cg;
+        const float* bp = a.gn.beta + cg;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 m4 = *reinterpret_cast<const float4*>(mp + 4 * h);
+            const float4 s4 = *reinterpret_cast<const float4*>(sp + 4 * h);
+            const float4 b4 = *reinterpret_cast<const float4*>(bp + 4 * h);
+            scv[2 * h] = f32x2{s4.x, s4.y};
+            scv[2 * h + 1] = f32x2{s4.z, s4.w};
+            shv[2 * h] = f32x2{fmaf(-m4.x, s4.x, b4.x), fmaf(-m4.y, s4.y, b4.y)};
+            shv[2 * h + 1] = f32x2{fmaf(-m4.z, s4.z, b4.z), fmaf(-m4.w, s4.w, b4.w)};
+        }
+    };
+    // The halo of chunk + 1 (raw pieces in RX, parameters (SCX, SHX)) is normalised in ONE burst into buffer HB, at a moment
+    // when the consumers issue no MFMA: next to a saturated MFMA stream every VALU instruction of the co-resident wave costs
+    // 7-10 cycles (tools/pc16_ts.py: 290 cycles per piece, 1 000-cycle steps against 512 cycles of MFMA), alone on the SIMD
+    // 2-4.  Paying ~900 cycles once per chunk beats ~3 000 spread under the MFMAs.
+#define FLOWSE_PC_BURST(RX, HINX, SCX, SHX, HB)                                                                      \
+    if (GN) {                                                                                                        \
+        /* stage by stage over ALL pieces (24 channel pairs): a lone wave hides no latency by itself -- piece after piece   \
+           the dependent unpack -> fma -> exp -> rcp -> mul chains ran at ~10 cycles per instruction (3 300 cycles per      \
+           burst, tools/pc16_ts.py); 24 independent pairs per stage keep the VALU issuing */                               \
+        f32x2 v[PC_PIECES][4], z[PC_PIECES][4];                                                                      \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
+            const unsigned wsrc[4] = {RX[q].x, RX[q].y, RX[q].z, RX[q].w};                                           \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
+                float u0, u1;                                                                                        \
+                St<T16>::unpack2(wsrc[e], u0, u1);                                                                   \
+                v[q][e] = f32x2{u0, u1};                                                                             \
+            }                                                                                                        \
+        }                                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e)          \
+            v[q][e] = __builtin_elementwise_fma(v[q][e], SCX[e], SHX[e]);                                            \
+        if (GN == 2) {                                                                                               \
+            const f32x2 nl2e = {-1.44269504088896341f, -1.44269504088896341f}, one = {1.f, 1.f};                     \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e)      \
+                z[q][e] = v[q][e] * nl2e;                                                                            \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e) {    \
+                z[q][e].x = __builtin_amdgcn_exp2f(z[q][e].x);                                                       \
+                z[q][e].y = __builtin_amdgcn_exp2f(z[q][e].y);                                                       \
+            }                                                                                                        \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e)      \
+                z[q][e] += one;                                                                                      \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e) {    \
+                z[q][e].x = __builtin_amdgcn_rcpf(z[q][e].x);                                                        \
+                z[q][e].y = __builtin_amdgcn_rcpf(z[q][e].y);                                                        \
+            }                                                                                                        \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e)      \
+                v[q][e] *= z[q][e];                                                                                  \
+        }                                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
+            const unsigned keepm = (((HINX) >> q) & 1u) ? 0xffffffffu : 0u;   /* zero padding AFTER the activation */ \
+            u32x4 t;                                                                                                 \
+            t.x = pc_pack2<F16>(v[q][0].x, v[q][0].y) & keepm;                                                       \
+            t.y = pc_pack2<F16>(v[q][1].x, v[q][1].y) & keepm;                                                       \
+            t.z = pc_pack2<F16>(v[q][2].x, v[q][2].y) & keepm;                                                       \
+            t.w = pc_pack2<F16>(v[q][3].x, v[q][3].y) & keepm;                                                       \
+            if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) * PC_HBUF_X + hlds[q]) = t;     \
+        }                                                                                                            \
+    } else {                                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q)                                                        \
+            if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) * PC_HBUF_X + hlds[q]) = RX[q]; \
+    }
+    // weight tile of (cursor CURV, tap TAPV): [128 output channels][32 channels], two 16-byte columns per thread.  The tiles
+    // travel through a ring of NINE register sets, i.e. they are requested a whole chunk (nine steps) before they are written to
+    // LDS: vector memory loads return in issue order, so a weight tile (an L2 hit) requested behind the halo pieces of the next
+    // chunk (first touch of those pixels: HBM, 2-4 us under load) is only visible once they have landed -- with a three-step
+    // ring the producers sat in s_waitcnt for ~300 cycles per step (tools/pc16_ts.py); nine steps outlast the HBM round trip.
+    u32x4 wr[9][2];
+#define FLOWSE_PC_WLOAD(RING, CURV, TAPV)                                                                            \
+    {                                                                                                                \
+        const Cur& cc = (CURV);                                                                                      \
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(                                              \
+            ((cc.p.n0 * 9 + (TAPV)) * Cin + cc.chunk * KC) * 2);                                                     \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                \
+            wr[RING][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo0 + q * bvo_step, soff, 0);                \
+    }
+#define FLOWSE_PC_WSTORE(RING, SL)                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                    \
+        *reinterpret_cast<u32x4*>(Ws + (SL) * PC_WSLOT + (brow0 + 64 * q) * PC_ROWB + bcol * 16) = wr[RING][q];
+
+    // ---- prologue: halo of chunk 0 -> buffer 0; weight tiles of steps 0, 1 -> slots 0, 1; ring <- steps 2 .. 10;
+    // rb <- raw halo of chunk 1 (normalised during chunk 0)
+    const Cur c0 = cursor(0);
+    Cur c1 = cursor(1), c2 = cursor(2);                    // cursors of the chunks gc + 1, gc + 2
+    FLOWSE_PC_HLOAD(ra, hin_a, c0)
+    load_params(c0, sca, sha);
+    FLOWSE_PC_WLOAD(0, c0, 0)
+    FLOWSE_PC_WLOAD(1, c0, 1)
+    FLOWSE_PC_HLOAD(rb, hin_b, c1)
+    FLOWSE_PC_BURST(ra, hin_a, sca, sha, 0)
+    FLOWSE_PC_WSTORE(0, 0)
+    FLOWSE_PC_WSTORE(1, 1)
+    FLOWSE_PC_WLOAD(2, c0, 2) FLOWSE_PC_WLOAD(3, c0, 3) FLOWSE_PC_WLOAD(4, c0, 4) FLOWSE_PC_WLOAD(5, c0, 5)
+    FLOWSE_PC_WLOAD(6, c0, 6) FLOWSE_PC_WLOAD(7, c0, 7) FLOWSE_PC_WLOAD(8, c0, 8)
+    FLOWSE_PC_WLOAD(0, c1, 0) FLOWSE_PC_WLOAD(1, c1, 1)
+    load_params(c1, scb, shb);
+    PC_TS_DECL
+    PC_TS_START
+    __syncthreads();                                       // (A)
+    PC_TS_ADD(2)
+
+    int cit = 0;
+    // One producer step at (chunk gc + GO, tap TAP): weights only -- write tile s + 2 (ring entry (TAP + 2) % 9) into LDS slot
+    // (TAP + 2) % 3, request tile s + 11 into the same entry; tap 0 also requests the raw halo of chunk + 2 into RY, tap 6 the
+    // GroupNorm parameters of chunk + 2 into (SCY, SHY).  CG1 / CG2: cursors of chunks gc + GO + 1, + 2.
+#define FLOWSE_PC_LSTEP(TAP, RY, HINY, SCY, SHY, CG1, CG2)                                                           \
+    {                                                                                                                \
+        constexpr int ring = ((TAP) + 2) % 9;              /* ring entry of step s + 2; its LDS slot is ring % 3 */ \
+        FLOWSE_PC_WSTORE(ring, ring % 3)                                                                             \
+        if constexpr ((TAP) + 2 < 9) { FLOWSE_PC_WLOAD(ring, CG1, (TAP) + 2) } else { FLOWSE_PC_WLOAD(ring, CG2, (TAP) + 2 - 9) } \
+        if constexpr ((TAP) == 0) { FLOWSE_PC_HLOAD(RY, HINY, CG2) }                                                 \
+        if constexpr ((TAP) == 6) load_params(CG2, SCY, SHY);                                                        \
+        PC_TS_ADD(0)                                       /* 0: producer work */                                   \
+        __syncthreads();                                                                                             \
+        PC_TS_ADD(1)                                       /* 1: producer at the step barrier */                    \
+    }
+    // One chunk: burst (T) for the next chunk of the same tile first; nine weight steps; at a tile's last chunk the burst for
+    // the NEXT tile's first chunk runs behind the steps, under the consumers' output stage, and ends at its barrier (S).
+#define FLOWSE_PC_LCHUNK(GO, RX, HINX, SCX, SHX, RY, HINY, SCY, SHY, CG1, CG2)                                       \
+    {                                                                                                                \
+        const bool tile_end = cit == nchunks - 1;                                                                    \
+        if (!tile_end) {                                                                                             \
+            FLOWSE_PC_BURST(RX, HINX, SCX, SHX, ((GO) + 1) & 1)                                                      \
+            PC_TS_ADD(4)                                   /* 4: halo burst */                                      \
+            __syncthreads();                               /* (T) */                                                \
+            PC_TS_ADD(1)                                                                                             \
+        }                                                                                                            \
+        FLOWSE_PC_LSTEP(0, RY, HINY, SCY, SHY, CG1, CG2) FLOWSE_PC_LSTEP(1, RY, HINY, SCY, SHY, CG1, CG2)            \
+        FLOWSE_PC_LSTEP(2, RY, HINY, SCY, SHY, CG1, CG2) FLOWSE_PC_LSTEP(3, RY, HINY, SCY, SHY, CG1, CG2)            \
+        FLOWSE_PC_LSTEP(4, RY, HINY, SCY, SHY, CG1, CG2) FLOWSE_PC_LSTEP(5, RY, HINY, SCY, SHY, CG1, CG2)            \
+        FLOWSE_PC_LSTEP(6, RY, HINY, SCY, SHY, CG1, CG2) FLOWSE_PC_LSTEP(7, RY, HINY, SCY, SHY, CG1, CG2)            \
+        FLOWSE_PC_LSTEP(8, RY, HINY, SCY, SHY, CG1, CG2)                                                             \
+        ++cit;                                                                                                       \
+        if (tile_end) {                                                                                              \
+            cit = 0;                                                                                                 \
+            if (gc + (GO) + 1 < Ctot) { FLOWSE_PC_BURST(RX, HINX, SCX, SHX, ((GO) + 1) & 1) }                        \
+            PC_TS_ADD(4)                                                                                             \
+            __syncthreads();                               /* (S) the consumers' output-stage barrier */            \
+            PC_TS_ADD(3)                                   /* 3: waiting for the consumers' output stage */         \
+        }                                                                                                            \
+    }
+    for (int gc = 0; gc < Ctot; gc += 2) {
+        // chunk gc: normalises rb (chunk gc + 1, parameters b), requests chunk gc + 2 into ra / a
+        FLOWSE_PC_LCHUNK(0, rb, hin_b, scb, shb, ra, hin_a, sca, sha, c1, c2)
+        if (gc + 1 < Ctot) {
+            const Cur c3 = cursor(gc + 3);
+            // chunk gc + 1: normalises ra (chunk gc + 2, parameters a), requests chunk gc + 3 into rb / b
+            FLOWSE_PC_LCHUNK(1, ra, hin_a, sca, sha, rb, hin_b, scb, shb, c2, c3)
+            c1 = c3;
+            c2 = cursor(gc + 4);
+        }
+    }
+#undef FLOWSE_PC_LCHUNK
+#undef FLOWSE_PC_BURST
+    if (wave == 4) { PC_TS_FLUSH(8) }                      // slots 8-15 of the block
+#undef FLOWSE_PC_LSTEP
+#undef FLOWSE_PC_WSTORE
+#undef FLOWSE_PC_WLOAD
+#undef FLOWSE_PC_HLOAD
+}
+
+// The producer / consumer form takes a 3x3 on 16-bit activations when its 16 x 16-pixel tiling applies and the launch
+// fills the chip at least once: >= 256 (tile, 128-channel block) items, i.e. everything from 64 x 64 up at batch 8.
+bool conv16_uses_pc(int B, int H, int W, int C1, int C2, int Cout, int taps) {
+    if (taps != 9 || (H & 15) || (W & 15) || (C1 % KC) || (C2 % KC) || (Cout % 128)) return false;
+    const int64_t cmax = C1 > C2 ? C1 : C2;
+    if ((int64_t)(17 * W + 18) * cmax * 2 >= (1LL << 31) || (int64_t)Cout * 9 * (C1 + C2) * 2 >= (1LL << 31)) return false;
+    return ((int64_t)B * H * W / 256) * (Cout / 128) >= 256;
+}
+
+int launch_pc16(const ConvArgs& a, hipStream_t s) {
+    if (a.in_dt == DT_F32 || a.in_dt != a.out_dt || a.terms != 1 || a.partial || !a.wq ||
+        (a.wq_f16 ? DT_F16 : DT_BF16) != a.in_dt || !conv16_uses_pc(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
+        set_error("pc16: 16-bit storage in = out = operand type, 16 x 16-pixel tiles, no split-K form");
+        return ERR_ARG;
+    }
+    int dev = 0, cus = 256;
+    FLOWSE_HIP(hipGetDevice(&dev));
+    static int cu_cache[64] = {0};
+    if (!cu_cache[dev & 63]) {
+        hipDeviceProp_t prop;
+        FLOWSE_HIP(hipGetDeviceProperties(&prop, dev));
+        cu_cache[dev & 63] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    cus = cu_cache[dev & 63];
+    const int64_t items = ((int64_t)a.B * a.H * a.W / 256) * (a.Cout / 128);
+    int grid = (int)(items < cus ? items : cus);
+    grid &= ~7;                                            // a multiple of the 8 XCDs (>= 256 items: never 0)
+    const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;
+#define FLOWSE_LPC(GNF, F16)                                                                         \
+    {                                                                                                \
+        if (const int rc = allow_lds<&conv3x3_pc16_kernel<GNF, F16>>(PC_LDS)) return rc;             \
+        hipLaunchKernelGGL((conv3x3_pc16_kernel<GNF, F16>), dim3(grid), dim3(512), PC_LDS, s, a);    \
+    }
+    if (a.wq_f16) {
+        if (gn == 2) FLOWSE_LPC(2, true) else if (gn == 1) FLOWSE_LPC(1, true) else FLOWSE_LPC(0, true)
+    } else {
+        if (gn == 2) FLOWSE_LPC(2, false) else if (gn == 1) FLOWSE_LPC(1, false) else FLOWSE_LPC(0, false)
+    }
+#undef FLOWSE_LPC
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+}  // namespace flowse

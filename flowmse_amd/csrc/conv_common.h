@@ -29,6 +29,8 @@ int launch_f43(const ConvArgs& a, hipStream_t s);              // conv_f43.hip: 
 int launch_halo_bf16x3(const ConvArgs& a, hipStream_t s);      // conv16.hip: split-bf16 operands, fp32 storage
 int launch_halo16_any(const ConvArgs& a, hipStream_t s);       // conv16.hip: 16-bit operands, LDS-halo 3x3
 int launch_flat16(const ConvArgs& a, hipStream_t s);           // conv16.hip: 16-bit storage, flat 1x1 / small 3x3
+int launch_pc16(const ConvArgs& a, hipStream_t s);             // conv16_pc.hip: 16-bit storage, producer / consumer LDS-halo 3x3
+bool conv16_uses_pc(int B, int H, int W, int C1, int C2, int Cout, int taps);
 
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with its own
 // L2); remapping so that every XCD walks a CONTIGUOUS range of tiles keeps the rows shared by vertically
@@ -303,135 +305,6 @@ __device__ __forceinline__ void tile128x64_out(const ConvArgs& a, const float* C
     }
 }
 
-// ---- output stage straight from the accumulators of a [MT x 128 pixels][128 channels] block tile held as 4 waves x
-// MT x 2 x 2 tiles of the 32x32 MFMA, 16-bit storage.  In the C/D layout a lane owns ONE output channel (col = lane & 31)
-// at 16 pixels of every tile, so the per-channel work -- bias, the GroupNorm partial statistics -- is in-lane arithmetic,
-// and no trip through LDS is needed to reach the NHWC rows: neighbouring lanes (channels c, c + 1) swap one value per
-// pixel pair through DPP, after which the even lane holds both channels at pixel r and the odd lane both at pixel r + 1.
-// Each then loads / stores ONE dword (two 16-bit channels); the 16 lane pairs of a half-wave cover 64 contiguous bytes
-// of an output pixel.  Per thread and tile: 8 loads (residual), 8 stores, ~20 VALU per pixel pair -- against two
-// block-wide passes through a 35 KB LDS tile, four barriers and half the waves idle in the staged form.
-// Statistics: pivoted (mean, M2) over the lane's 16 values per channel, equal-count merges lane pair -> half-waves ->
-// the two waves that share the channels (through `red`, [2][MT][128][2] floats of LDS).  All 256 threads must call;
-// every wave must be past its last read of the LDS that `red` overlays.
-template <class OT, int MT>
-__device__ __forceinline__ void halo16_out_direct(const ConvArgs& a, f32x16 (&acc)[MT][2][2], float* red, int m_tl, int W,
-                                                  int n0, int bsmp, int tile0, int tiles_x) {
-    static_assert(sizeof(OT) == 2, "16-bit storage only");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kh = lane >> 5;
-    const bool odd = li & 1;
-    const int Cout = a.Cout;
-    const bool has_res = a.res != nullptr;
-    const unsigned* resw = reinterpret_cast<const unsigned*>(reinterpret_cast<const OT*>(a.res) + (int64_t)m_tl * Cout);
-    unsigned* outw = reinterpret_cast<unsigned*>(reinterpret_cast<OT*>(a.out) + (int64_t)m_tl * Cout);
-    // dword offset of this lane's channel pair at tile pixel 0, plus its pixel inside the 4-pixel group (odd + 4 kh)
-    const int lane_off = ((odd ? 1 : 0) + 4 * kh) * (Cout >> 1) + ((n0 + wn * 64 + (li & ~1)) >> 1);
-    float bq[2][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = n0 + wn * 64 + j * 32 + (li & ~1);
-        bq[j][0] = a.bias ? a.bias[c] : 0.f;
-        bq[j][1] = a.bias ? a.bias[c + 1] : 0.f;
-        if (a.bias2) {
-            const float* b2 = a.bias2 + (int64_t)bsmp * a.bias2_stride + c;
-            bq[j][0] += b2[0];
-            bq[j][1] += b2[1];
-        }
-    }
-    const float scale = a.scale;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        float piv[2][2], s1[2][2], s2[2][2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) { piv[j][e] = 0.f; s1[j][e] = 0.f; s2[j][e] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            // tile row of pixel pair p: rho = 2 (p & 1) + 8 ((p >> 1) & 1) + 16 (p >> 2) [+ odd + 4 kh]: image row p >> 2
-            const int row_off = ((t * 8 + 2 * (wm * 2 + i)) * W) * (Cout >> 1) + lane_off;
-            const int row_step = W * (Cout >> 1);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                unsigned rres[8];
-                int off[8];
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    off[p] = row_off + (p >> 2) * row_step + (2 * (p & 1) + 8 * ((p >> 1) & 1)) * (Cout >> 1) + j * 16;
-                    if (has_res) rres[p] = resw[off[p]];
-                }
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    const float lo = acc[t][i][j][2 * p], hi = acc[t][i][j][2 * p + 1];
-                    const float send = odd ? lo : hi;
-                    const float recv = __builtin_bit_cast(
-                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));
-                    float v0 = (odd ? recv : lo) + bq[j][0];          // channel pair (c, c + 1) at this lane's pixel
-                    float v1 = (odd ? hi : recv) + bq[j][1];
-                    if (has_res) {
-                        float r0, r1;
-                        St<OT>::unpack2(rres[p], r0, r1);
-                        v0 += r0;
-                        v1 += r1;
-                    }
-                    v0 *= scale;
-                    v1 *= scale;
-                    const unsigned w = St<OT>::pack2(v0, v1);
-                    outw[off[p]] = w;
-                    St<OT>::unpack2(w, v0, v1);                        // statistics of what was stored
-                    if (i == 0 && p == 0) { piv[j][0] = v0; piv[j][1] = v1; }
-                    const float d0 = v0 - piv[j][0], d1 = v1 - piv[j][1];
-                    s1[j][0] += d0; s2[j][0] = fmaf(d0, d0, s2[j][0]);
-                    s1[j][1] += d1; s2[j][1] = fmaf(d1, d1, s2[j][1]);
-                }
-            }
-        }
-        if (!a.stats) continue;
-        // 16 values per lane and channel -> lane pair (32) -> half-waves (64 = this wave's pixels of the sub-tile)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float mean = piv[j][e] + s1[j][e] * (1.f / 16);
-                float m2 = fmaxf(s2[j][e] - s1[j][e] * s1[j][e] * (1.f / 16), 0.f);
-                {
-                    const float mo = __builtin_bit_cast(
-                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mean), 0xB1, 0xF, 0xF, false));
-                    const float qo = __builtin_bit_cast(
-                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m2), 0xB1, 0xF, 0xF, false));
-                    const float d = mo - mean;
-                    m2 = m2 + qo + d * d * 8.f;
-                    mean = 0.5f * (mean + mo);
-                }
-                {
-                    const float mo = __shfl_xor(mean, 32), qo = __shfl_xor(m2, 32);
-                    const float d = mo - mean;
-                    m2 = m2 + qo + d * d * 16.f;
-                    mean = 0.5f * (mean + mo);
-                }
-                if (kh == 0 && !odd) {
-                    float* dst = red + (((wm * MT + t) * 128) + wn * 64 + j * 32 + li + e) * 2;
-                    dst[0] = mean;
-                    dst[1] = m2;
-                }
-            }
-    }
-    if (!a.stats) return;
-    __syncthreads();
-    if (tid < 128) {
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const float ma = red[((0 * MT + t) * 128 + tid) * 2], qa = red[((0 * MT + t) * 128 + tid) * 2 + 1];
-            const float mb = red[((1 * MT + t) * 128 + tid) * 2], qb = red[((1 * MT + t) * 128 + tid) * 2 + 1];
-            const float d = mb - ma;
-            float* dst = a.stats + (((int64_t)bsmp * a.stats_nblk + tile0 + t * tiles_x) * Cout + n0 + tid) * 2;
-            dst[0] = 0.5f * (ma + mb);
-            dst[1] = qa + qb + d * d * 32.f;
-        }
-    }
-}
-
 // buffer loads: out-of-image taps (conv zero padding), rows past M and channels past Cout are redirected to an
 // out-of-range buffer offset, for which the hardware returns 0 -- no masking VALU, no branches
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -494,34 +367,5 @@ __device__ __forceinline__ u32x4 gn_quad(u32x4 raw, float4 mu, float4 sc, float4
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-// raw (un-widened) channel quad: 4 dwords for float, 2 for the 16-bit types
-template <class ST> struct RawQuad { typedef u32x4 type; };
-template <> struct RawQuad<bf16_t> { typedef unsigned int type __attribute__((ext_vector_type(2))); };
-template <> struct RawQuad<f16_t> { typedef unsigned int type __attribute__((ext_vector_type(2))); };
-template <class ST>
-__device__ __forceinline__ typename RawQuad<ST>::type buf_ld_raw(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    if constexpr (std::is_same<ST, float>::value) return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    else return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-}
-template <class ST>
-__device__ __forceinline__ u32x4 widen_quad(typename RawQuad<ST>::type t) {
-    if constexpr (std::is_same<ST, float>::value) {
-        return t;
-    } else if constexpr (std::is_same<ST, bf16_t>::value) {
-        u32x4 o;
-        o.x = t.x << 16; o.y = t.x & 0xffff0000u; o.z = t.y << 16; o.w = t.y & 0xffff0000u;
-        return o;
-    } else {
-        const _Float16 e0 = __builtin_bit_cast(_Float16, (unsigned short)(t.x & 0xffffu));
-        const _Float16 e1 = __builtin_bit_cast(_Float16, (unsigned short)(t.x >> 16));
-        const _Float16 e2 = __builtin_bit_cast(_Float16, (unsigned short)(t.y & 0xffffu));
-        const _Float16 e3 = __builtin_bit_cast(_Float16, (unsigned short)(t.y >> 16));
-        u32x4 o;
-        o.x = __float_as_uint((float)e0); o.y = __float_as_uint((float)e1);
-        o.z = __float_as_uint((float)e2); o.w = __float_as_uint((float)e3);
-        return o;
-    }
-}
 
 }  // namespace flowse

@@ -368,12 +368,18 @@ def _conv16(x, w, dt, bias=None, x2=None, res=None, gn=None, scale=1.0):
 
 
 @pytest.mark.parametrize("dt,bound", [(1, 4e-3), (2, 5e-4)])
-@pytest.mark.parametrize("case", ["halo", "halo_gn_concat", "halo_32ch", "flat_small_splitk", "flat_1x1_concat", "flat_w8"])
+@pytest.mark.parametrize("case", ["halo", "halo_gn_concat", "halo_32ch", "flat_small_splitk", "flat_1x1_concat", "flat_w8",
+                                  "pc", "pc_gn_concat", "pc_gn_256out", "pc_ragged_items"])
 def test_conv2d_16bit_storage(case, dt, bound):
+    """pc*: >= 256 (16 x 16 pixel tile, 128-channel block) items -> the persistent producer / consumer kernel
+    (conv3x3_pc16_kernel); pc_ragged_items: an item count that is no multiple of the 256 blocks (blocks with 1 and 2 tiles,
+    tiles of several samples and both channel blocks in one block's stream)."""
     g = torch.Generator().manual_seed(3)
     shapes = {"halo": (2, 128, 0, 128, 64, 128, 3), "halo_gn_concat": (2, 128, 128, 128, 64, 128, 3),
               "halo_32ch": (2, 32, 0, 128, 64, 128, 3), "flat_small_splitk": (2, 256, 0, 256, 16, 16, 3),
-              "flat_1x1_concat": (2, 256, 128, 128, 32, 64, 1), "flat_w8": (3, 256, 0, 256, 8, 8, 3)}
+              "flat_1x1_concat": (2, 256, 128, 128, 32, 64, 1), "flat_w8": (3, 256, 0, 256, 8, 8, 3),
+              "pc": (1, 128, 0, 128, 256, 256, 3), "pc_gn_concat": (4, 64, 32, 128, 128, 128, 3),
+              "pc_gn_256out": (2, 64, 0, 256, 128, 128, 3), "pc_ragged_items": (3, 32, 0, 256, 112, 128, 3)}
     B, C1, C2, Cout, H, W, k = shapes[case]
     C = C1 + C2
     x = torch.randn(B, C, H, W, generator=g)
@@ -381,7 +387,7 @@ def test_conv2d_16bit_storage(case, dt, bound):
     bias = torch.randn(Cout, generator=g)
     res = torch.randn(B, Cout, H, W, generator=g)
     gn, xin = None, x
-    if case == "halo_gn_concat":
+    if case in ("halo_gn_concat", "pc_gn_concat", "pc_gn_256out"):
         mean = 0.2 * torch.randn(B, C, generator=g)
         scl = 1 + 0.2 * torch.randn(B, C, generator=g)
         beta = 0.2 * torch.randn(C, generator=g)
