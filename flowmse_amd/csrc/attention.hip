@@ -181,12 +181,206 @@ static int launch_att(const float* qkv, int B, int L, float* out, hipStream_t s)
     return OK;
 }
 
-int launch_attention(const float* qkv, int B, int L, int C, float* out, hipStream_t s) {
+
+// ---------------------------------------------------------------------------------------------------
+// 16-bit form for the bf16 / fp16 storage modes (BASELINE configs 2 / 4: "MFMA attention"): q / k / v arrive as 16-bit
+// tokens from the 16-bit qkv projection, both products run on v_mfma_f32_32x32x16_{bf16,f16} (one instruction = 16
+// channels of Q K^T or 16 keys of P V: 16x fewer matrix instructions than the fp32 form), softmax state and the O
+// accumulators stay fp32, the result is rounded once to the storage type.  Same transposed formulation and the same
+// 8-wave split of the key tiles as attention_kernel.  P^T reaches the second product straight from the S^T accumulator
+// registers: the instruction's K index j (0..7) of lane half kh is register 8 u + j of MFMA u = key
+// ((8u + j) & 3) + 8 ((8u + j) >> 2) + 4 kh of the tile -- any order works as long as the V operand uses the same one.
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 af16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int au32x4 __attribute__((ext_vector_type(4)));
+
+template <int NCT, class ST>
+__global__ __launch_bounds__(64 * ATT_WAVES) void attention16_kernel(const ST* __restrict__ qkv, int L, ST* __restrict__ out,
+                                                                     float scale) {
+    constexpr bool F16 = St<ST>::dt == DT_F16;
+    constexpr int C = 32 * NCT;
+    constexpr int QROWB = C * 2 + 16;                   // bytes per staged query row (16 B pad: conflict-free b128 reads)
+    constexpr int OROW = C + 4;                         // floats per row of the merged O tile
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    char* Qs = reinterpret_cast<char*>(sm);             // [32][QROWB] 16-bit query tile; later (fp32) the merged O tile
+    float* sm_m = sm + 32 * OROW;                       // [ATT_WAVES][32]
+    float* sm_l = sm_m + ATT_WAVES * 32;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.y, q0 = blockIdx.x * 32;
+    const int64_t rs = 3 * C;                           // token stride (elements)
+    const ST* base = qkv + (int64_t)b * L * rs;
+
+    for (int i = tid; i < 32 * (C / 8); i += 64 * ATT_WAVES) {          // query tile, 16 bytes per thread (zero rows beyond L)
+        const int r = i / (C / 8), c8 = i - r * (C / 8);
+        au32x4 v = {0u, 0u, 0u, 0u};
+        if (q0 + r < L) v = *reinterpret_cast<const au32x4*>(base + (int64_t)(q0 + r) * rs + c8 * 8);
+        *reinterpret_cast<au32x4*>(Qs + r * QROWB + c8 * 16) = v;
+    }
+    __syncthreads();
+
+    f32x16 o[NCT];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = wave * 32; k0 < L; k0 += 32 * ATT_WAVES) {
+        // ---- S^T tile: C / 16 MFMAs, the key row of this lane as 16-byte pieces (all requested up front: C / 16 <= 16)
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const int krow = k0 + li;
+        const bool kok = krow < L;
+        const ST* kp = base + (int64_t)(kok ? krow : 0) * rs + C + kh * 8;
+        au32x4 ak[C / 16];
+#pragma unroll
+        for (int j = 0; j < C / 16; ++j) {
+            ak[j] = *reinterpret_cast<const au32x4*>(kp + j * 16);
+            if (!kok) ak[j] = au32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < C / 16; ++j) {
+            const au32x4 q = *reinterpret_cast<const au32x4*>(Qs + li * QROWB + (j * 16 + kh * 8) * 2);
+            if (F16)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(af16x8, ak[j]), __builtin_bit_cast(af16x8, q), s, 0, 0, 0);
+            else
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, ak[j]), __builtin_bit_cast(abf16x8, q), s, 0, 0, 0);
+        }
+        // ---- online softmax over keys (fp32), as in the fp32 kernel
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            s[r] = key < L ? s[r] * scale : -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = expf(s[r] - m_new);
+            psum += s[r];
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // P^T operands: registers 8u .. 8u + 7 rounded to the storage type (the normaliser l above sums the UNROUNDED
+        // probabilities, like the reference's softmax followed by a 16-bit matmul would)
+        au32x4 pb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pb[u].x = St<ST>::pack2(s[8 * u + 0], s[8 * u + 1]);
+            pb[u].y = St<ST>::pack2(s[8 * u + 2], s[8 * u + 3]);
+            pb[u].z = St<ST>::pack2(s[8 * u + 4], s[8 * u + 5]);
+            pb[u].w = St<ST>::pack2(s[8 * u + 6], s[8 * u + 7]);
+        }
+        // ---- O^T = alpha O^T + V^T P^T: per channel tile two MFMAs; A = V[key(u, j, kh)][channel 32 t + li], gathered
+        const unsigned short* vb = reinterpret_cast<const unsigned short*>(base) + 2 * C + li;
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            unsigned short vv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const unsigned short v = vb[(int64_t)(key < L ? key : 0) * rs + t * 32];
+                vv[r] = key < L ? v : (unsigned short)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                au32x4 va;
+                va.x = (unsigned)vv[8 * u + 0] | ((unsigned)vv[8 * u + 1] << 16);
+                va.y = (unsigned)vv[8 * u + 2] | ((unsigned)vv[8 * u + 3] << 16);
+                va.z = (unsigned)vv[8 * u + 4] | ((unsigned)vv[8 * u + 5] << 16);
+                va.w = (unsigned)vv[8 * u + 6] | ((unsigned)vv[8 * u + 7] << 16);
+                if (F16)
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(af16x8, va), __builtin_bit_cast(af16x8, pb[u]), o[t], 0, 0, 0);
+                else
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, va), __builtin_bit_cast(abf16x8, pb[u]), o[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- merge the per-wave states (fp32), exactly as in the fp32 kernel
+    if (kh == 0) {
+        sm_m[wave * 32 + li] = m_run;
+        sm_l[wave * 32 + li] = l_run;
+    }
+    __syncthreads();                       // also: every wave is done reading Qs
+    float m_tot = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < ATT_WAVES; ++w) m_tot = fmaxf(m_tot, sm_m[w * 32 + li]);
+    float l_tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < ATT_WAVES; ++w) l_tot += sm_l[w * 32 + li] * expf(sm_m[w * 32 + li] - m_tot);
+    const float f = expf(m_run - m_tot);
+    float* Os = sm;                        // merged O[query][channel] fp32, row stride OROW (overlays the query tile)
+#pragma unroll 1
+    for (int w = 0; w < ATT_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NCT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4* p = reinterpret_cast<float4*>(Os + li * OROW + t * 32 + 8 * g + 4 * kh);
+                    float4 v = make_float4(o[t][4 * g] * f, o[t][4 * g + 1] * f, o[t][4 * g + 2] * f, o[t][4 * g + 3] * f);
+                    if (w > 0) {
+                        const float4 old = *p;
+                        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                    }
+                    *p = v;
+                }
+        }
+        __syncthreads();
+    }
+    if (kh == 0 && wave == 0) sm_l[li] = l_tot;
+    __syncthreads();
+    for (int i = tid; i < 32 * (C / 4); i += 64 * ATT_WAVES) {
+        const int r = i / (C / 4), c4 = i - r * (C / 4);
+        if (q0 + r >= L) continue;
+        const float inv = 1.f / sm_l[r];
+        const float4 v = *reinterpret_cast<const float4*>(Os + r * OROW + c4 * 4);
+        St<ST>::st4(out + ((int64_t)b * L + q0 + r) * C + c4 * 4, make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv));
+    }
+}
+
+template <int NCT, class ST>
+static int launch_att16(const void* qkv, int B, int L, void* out, hipStream_t s) {
+    constexpr int C = 32 * NCT;
+    const size_t lds = (32 * (C + 4) + 2 * ATT_WAVES * 32) * sizeof(float);      // the fp32 O tile is the larger overlay
+    const dim3 grid((L + 31) / 32, B), block(64 * ATT_WAVES);
+    hipLaunchKernelGGL((attention16_kernel<NCT, ST>), grid, block, lds, s, static_cast<const ST*>(qkv), L, static_cast<ST*>(out),
+                       1.0f / sqrtf((float)C));
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
+}
+
+int launch_attention(const void* qkv, int B, int L, int C, void* out, hipStream_t s, int dt) {
+    if (dt != DT_F32) {
+#define FLOWSE_ATT16(NCT) (dt == DT_BF16 ? launch_att16<NCT, bf16_t>(qkv, B, L, out, s) : launch_att16<NCT, f16_t>(qkv, B, L, out, s))
+        switch (C) {
+            case 32:  return FLOWSE_ATT16(1);
+            case 64:  return FLOWSE_ATT16(2);
+            case 128: return FLOWSE_ATT16(4);
+            case 256: return FLOWSE_ATT16(8);
+            default: break;
+        }
+#undef FLOWSE_ATT16
+        set_error("attention: unsupported channel count %d (32/64/128/256)", C);
+        return ERR_SHAPE;
+    }
+    const float* q = static_cast<const float*>(qkv);
+    float* o = static_cast<float*>(out);
     switch (C) {
-        case 32:  return launch_att<1>(qkv, B, L, out, s);
-        case 64:  return launch_att<2>(qkv, B, L, out, s);
-        case 128: return launch_att<4>(qkv, B, L, out, s);
-        case 256: return launch_att<8>(qkv, B, L, out, s);
+        case 32:  return launch_att<1>(q, B, L, o, s);
+        case 64:  return launch_att<2>(q, B, L, o, s);
+        case 128: return launch_att<4>(q, B, L, o, s);
+        case 256: return launch_att<8>(q, B, L, o, s);
         default:
             set_error("attention: unsupported channel count %d (32/64/128/256)", C);
             return ERR_SHAPE;

@@ -351,8 +351,9 @@ int launch_upfirdn2d_nchw(const float* in, const float* kernel, int planes, int 
                           int pad_y0, int pad_y1, float* out, int out_h, int out_w, hipStream_t s);
 
 // ------------------------------------------------------------------ attention
-// qkv: [B][L][3C] (q | k | v per token), out: [B][L][C]; softmax(q k^T * C^-1/2) v, single head
-int launch_attention(const float* qkv, int B, int L, int C, float* out, hipStream_t s);
+// qkv: [B][L][3C] (q | k | v per token), out: [B][L][C]; softmax(q k^T * C^-1/2) v, single head.  dt = storage type of qkv AND
+// out: fp32 (v_mfma_f32_32x32x2_f32) or bf16 / half (v_mfma_f32_32x32x16_*, fp32 softmax state and accumulation)
+int launch_attention(const void* qkv, int B, int L, int C, void* out, hipStream_t s, int dt = DT_F32);
 
 // ------------------------------------------------------------------ small ops
 // Per-call arguments of the network's boundary kernels (feature pack, time embedding, head).  They live in DEVICE

@@ -47,7 +47,7 @@ bool conv_force_generic() { return g_force_generic; }
 int f43_plan(int B, int H, int W, int Cin, int Cout, int taps) {
     if (g_no_wino_policy || taps != 9 || (H & 7) || (W & 15) || (Cin % KC) || (Cout % 64)) return 0;
     const int64_t blocks = ((int64_t)B * H * W / 128) * (Cout / 64);
-    if (blocks >= 256) return 1;
+    if (blocks >= 256) return 1;                      // (round 4 sweep: 128 / 512 / 1024 all lose at B = 1, 4, 8: profiles/r04_policy_sweep.md)
     const int nchunks = Cin / KC;
     if (blocks < 16 || nchunks < 4) return 0;
     int64_t ks = (512 + blocks - 1) / blocks;
@@ -68,7 +68,7 @@ int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     const int wp = f43_plan(B, H, W, Cin, Cout, taps);
     if (wp >= 1) return wp;
     int64_t want = (512 + tiles - 1) / tiles;
-    int64_t maxs = steps / 4;
+    int64_t maxs = steps / 4;                         // (>= 4 K steps per slice: 2 and 1 lose, same sweep)
     int64_t ks = want < maxs ? want : maxs;
     if (ks < 1) ks = 1;
     // make every slice non-empty

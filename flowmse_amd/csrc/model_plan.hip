@@ -433,16 +433,18 @@ struct Builder {
         flowse_model* M = m;
         const float rs2 = 0.70710678118654752440f;
         const int C = x.C, L = x.H * x.W, Bn = B;
-        // the attention sub-block keeps fp32 intermediates in every mode (0.3 % of the FLOPs): GroupNorm widens, the
-        // output projection rounds back to the activation type while adding the skip
-        Tn hn = gn_norm(x, nullptr, mod.w_gn0_g, mod.w_gn0_b, false, DT_F32);
+        // 16-bit storage modes: the whole sub-block stays in the activation type -- GroupNorm rounds to it, the qkv
+        // projection and the output projection run the 16-bit flat kernel, the attention core the 16-bit MFMA kernel
+        // (fp32 softmax state / accumulation); fp32 mode: everything fp32
+        const int adt = x.dt;
+        Tn hn = gn_norm(x, nullptr, mod.w_gn0_g, mod.w_gn0_b, false, adt);
         Tn qkv = conv("attn_qkv", hn, nullptr, mod.w_qkv, mod.w_qkv_b, -1, 3 * C, 1, nullptr, 1.f, false, false, nullptr,
-                      false, -1, DT_F32);
+                      false, -1, adt);
         release(hn);
-        Tn o = alloc(x.H, x.W, C, DT_F32);
+        Tn o = alloc(x.H, x.W, C, adt);
         const size_t q_off = qkv.off, o_off = o.off;
-        op("attention@" + std::to_string(x.H) + "x" + std::to_string(x.W), [=](hipStream_t s) { return launch_attention(M->A(q_off), Bn, L, C, M->A(o_off), s); },
-           4.0 * Bn * (double)L * L * C, 16.0 * Bn * L * C);
+        op("attention@" + std::to_string(x.H) + "x" + std::to_string(x.W), [=](hipStream_t s) { return launch_attention(M->A(q_off), Bn, L, C, M->A(o_off), s, adt); },
+           4.0 * Bn * (double)L * L * C, 4.0 * dt_size(adt) * Bn * L * C);
         release(qkv);
         Tn out = conv("attn_out", o, nullptr, mod.w_o, mod.w_o_b, -1, C, 1, &x, rs2, false, false, nullptr, false, -1,
                       x.dt);
