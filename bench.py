@@ -392,7 +392,7 @@ def main():
     Y = torch.cat([torch.from_numpy(synth.synth_spectrogram(rank * B + i, 1, F, T)) for i in range(B)]).to(dev)
     Z = torch.cat([torch.from_numpy(synth.synth_noise(rank * B + i, 1, F, T)) for i in range(B)]).to(dev)
     ws_bytes = model.dnn.reserve(B, F, T)
-    graphs_on = bool(os.environ.get("FLOWSE_GRAPH")) and not os.environ.get("FLOWSE_NO_GRAPH")   # opt-in (slower)
+    graphs_on = bool(os.environ.get("FLOWSE_GRAPH"))             # opt-in (slower)
 
     def step():
         sampler = get_white_box_solver(args.solver, model.ode, model, Y=Y, Y_prior=Y, T_rev=1.0, t_eps=0.03, N=NS, z=Z)

@@ -591,7 +591,7 @@ static int launch_halo_bf16(const ConvArgs& a, hipStream_t s) {
 int launch_halo_bf16x3(const ConvArgs& a, hipStream_t s) { return launch_halo_bf16<3>(a, s); }
 
 // 16-bit operands (terms = 1), fp32 or 16-bit storage, on launches the producer / consumer kernel (conv16_pc.hip) does not
-// take: fewer than 256 of its items, H not a multiple of 16, fp32 storage (FLOWSE_FP32_STORAGE=1)
+// take: fewer than 256 of its items, H not a multiple of 16, fp32 storage (networks whose channel counts do not tile)
 int launch_halo16_any(const ConvArgs& a, hipStream_t s) {
     return a.wq_f16 ? launch_halo_bf16<1, true>(a, s) : launch_halo_bf16<1>(a, s);
 }

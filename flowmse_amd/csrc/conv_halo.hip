@@ -342,8 +342,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_head4_kernel(ConvArgs a) {
 }
 
 bool conv_supports_head4(int B, int H, int W, int C1, int C2, int Cout, int taps) {
-    static const bool off = getenv("FLOWSE_NO_HEAD4") != nullptr;      // test / A-B hook
-    return !off && !conv_force_generic() && taps == 9 && Cout == 4 && C2 == 0 && (C1 % KC) == 0 && !(H & 15) && !(W & 15) &&
+    return !conv_force_generic() && taps == 9 && Cout == 4 && C2 == 0 && (C1 % KC) == 0 && !(H & 15) && !(W & 15) &&
            (int64_t)B * (H >> 4) * (W >> 4) >= 64 && (int64_t)(17 * W + 18) * C1 * 4 < (1LL << 31);
 }
 
@@ -469,8 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_cin4_mfma_kernel(ConvArgs a) {
 }
 
 bool conv_cin4_uses_mfma(int B, int H, int W, int Cout, int taps) {
-    static const bool off = getenv("FLOWSE_NO_CIN4_MFMA") != nullptr;      // test / A-B hook
-    return !off && taps == 9 && Cout == 128 && ((H * W) % 128) == 0 && (int64_t)B * H * W >= 128 * 256 && !conv_force_generic();
+    return taps == 9 && Cout == 128 && ((H * W) % 128) == 0 && (int64_t)B * H * W >= 128 * 256 && !conv_force_generic();
 }
 
 int launch_conv_cin4(const ConvArgs& a, hipStream_t s) {

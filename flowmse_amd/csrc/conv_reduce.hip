@@ -125,9 +125,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(ConvArgs a, in
 // subtraction mean^2 loses log2(mean^2 / var) of 53 bits -- see gn_group_stats in norm.hip).
 constexpr int RG_MAXQ = 32;
 bool conv_reduce_gn_ok(int B, int HW, int Cout) {
-    static const bool off = getenv("FLOWSE_NO_REDUCE_GN") != nullptr;
     const int G = Cout / 4 < 32 ? Cout / 4 : 32;
-    if (off || G <= 0 || (Cout % G) != 0) return false;
+    if (G <= 0 || (Cout % G) != 0) return false;
     // one block per (group, sample): with fewer than ~128 blocks the launch is slower than the two it replaces -- measured
     // at [1,1,256,256] (32 blocks, each pulling up to 512 KB of slices through one CU): 8.27 k vs 8.67 k frames/s
     if ((int64_t)B * G < 128) return false;

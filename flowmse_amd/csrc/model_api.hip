@@ -236,8 +236,8 @@ int flowse_model_create(const flowse_config* cfg, flowse_model** out) {
     // hipGraph replay of the launch list is opt-in (FLOWSE_GRAPH=1): measured on MI355X / ROCm 7.2 a replayed graph of
     // ~400 short kernel nodes runs 5 % SLOWER than the same launches issued eagerly from the C loop at [1,1,256,256]
     // (8.09 k vs 8.55 k frames/s) and equal at [8,1,256,256]; the host is nowhere near launch-bound (~1.5 ms of launch
-    // calls per 6 ms network evaluation at batch 1).  FLOWSE_NO_GRAPH=1 is accepted for compatibility.
-    m->use_graph = getenv("FLOWSE_GRAPH") != nullptr && getenv("FLOWSE_NO_GRAPH") == nullptr;
+    // calls per 6 ms network evaluation at batch 1).
+    m->use_graph = getenv("FLOWSE_GRAPH") != nullptr;
     const int rc = build_structure(m);
     if (rc != OK) {
         delete m;

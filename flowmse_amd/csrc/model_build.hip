@@ -28,7 +28,7 @@ static bool in_list(const int32_t* v, int n, int x) {
 // 16-bit storage applies when every wide tensor of the network has a multiple of 32 channels (what the 16-bit
 // matrix-core kernels tile by); otherwise precision 2 / 3 only switch the operands of the big 3x3 convs (fp32 storage).
 int storage_type_for(const flowse_model* m) {
-    if (m->precision < 2 || getenv("FLOWSE_FP32_STORAGE")) return DT_F32;
+    if (m->precision < 2) return DT_F32;
     for (const auto& mod : m->mods) {
         if (mod.kind == M_RESBLOCK || mod.kind == M_ATTN || mod.kind == M_GN)
             if ((mod.in_ch % 32) || (mod.out_ch % 32)) return DT_F32;

@@ -117,7 +117,7 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
  *   weights is kept), accumulators, GroupNorm statistics, time-embedding tables, split-K slabs, the 4-channel pyramid
  *   tensors and the interior of the attention blocks stay fp32.  Applies to networks whose wide channel counts are
  *   multiples of 32 (the released configuration); otherwise storage stays fp32 and only the operands of the 3x3 convs
- *   with Cout % 128 == 0 become 16-bit.  FLOWSE_FP32_STORAGE=1 forces that operand-only form.
+ *   with Cout % 128 == 0 become 16-bit.
  * The boundary tensors (x, y, out: complex64; t: float32) are the same in every mode. */
 int flowse_model_set_precision(flowse_model* m, int mode);
 

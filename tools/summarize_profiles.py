@@ -98,6 +98,32 @@ def main(tag):
             f.write(f"fp32 matrix peak at that clock: {64 * 1024 * cyc / dur / 1e3:.1f} TFLOP/s "
                     "(64 FLOP/clk/SIMD x 1024 SIMD)\n")
         print("wrote", os.path.join(P, f"{tag}_pmc_dominant_kernel.txt"))
+    sq16 = os.path.join(G, "prof_sq16", f"{tag}_counter_collection.csv")
+    if os.path.exists(sq16):                                # SQ counters of the 16-bit producer / consumer conv (bf16 run)
+        vals, durs, name = collections.defaultdict(list), [], None
+        with open(sq16) as f:
+            for r in csv.DictReader(f):
+                if "conv3x3_pc16_kernel<2" in r["Kernel_Name"]:
+                    name = r["Kernel_Name"][:120]
+                    vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                        durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        if durs:
+            m = {k: sum(v) / len(v) for k, v in vals.items()}
+            dur = sum(durs) / len(durs)
+            cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+            with open(os.path.join(P, f"{tag}_pmc_bf16_kernel.txt"), "w") as f:
+                f.write("# rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+                        "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- python bench.py --steps 1 --warmup 1 "
+                        "--precision bf16 --no-cpu-baseline --no-alt\n")
+                f.write(f"# kernel: {name}, {len(durs)} launches (all its shapes at [8,1,256,256], N=5), avg {dur / 1e3:.1f} us "
+                        "(profiled run)\n")
+                for k in sorted(m):
+                    f.write(f"{k:28s} per launch {m[k]:.4e}\n")
+                f.write(f"effective clock (GRBM_GUI_ACTIVE / 8 XCD / duration): {cyc / dur:.2f} GHz\n")
+                f.write("MFMA busy fraction per SIMD (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMD x cycles)): "
+                        f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.3f}\n")
+            print("wrote", os.path.join(P, f"{tag}_pmc_bf16_kernel.txt"))
     for k in dom:
         print(k, out[k])
 
