@@ -279,9 +279,9 @@ def dist_info(world, backend):
 DTYPE_NAMES = {"fp32": "f32",
                "bf16x3": "f32 (3x3 convs as split-bf16 x3 MFMA, fp32 accumulate)",
                "bf16": "bf16 activation storage + bf16 matrix-core operands (fp32 accumulate, GroupNorm statistics, "
-                       "4-channel tensors and attention interior)",
+                       "softmax state and 4-channel tensors)",
                "fp16": "fp16 activation storage + fp16 matrix-core operands (fp32 accumulate, GroupNorm statistics, "
-                       "4-channel tensors and attention interior)"}
+                       "softmax state and 4-channel tensors)"}
 
 
 def spawn_ranks(n):
@@ -487,7 +487,9 @@ def main():
                      "GroupNorm+SiLU input, weights streamed from L2 in MFMA fragment order)" if form else
                      "flowse::conv3x3_halo_kernel<2,2,2,2,2> (fp32 implicit-GEMM 3x3 conv, 128x128 tile, LDS halo, "
                      "fused GroupNorm+SiLU input)" if args.precision == "fp32" else
-                     "flowse::conv3x3_halo16_kernel / conv3x3_halo_bf16_kernel (16-bit operand LDS-halo 3x3 kernels)")
+                     "flowse::conv3x3_halo_bf16_kernel (fp32 storage, split-bf16 x3 operands, LDS halo)" if args.precision == "bf16x3" else
+                     "flowse::conv3x3_pc16_kernel (+ conv3x3_halo_bf16_kernel on small launches): persistent producer/consumer "
+                     "LDS-halo 3x3 conv, 16-bit MFMA operands, fused GroupNorm+SiLU input")
             issue = {"F(4,3)": 0.5, None: 3.0 if args.precision == "bf16x3" else 1.0}[form]
             issued = ach * issue
             peak = PEAK_FP32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_16BIT_MATRIX_TFLOPS
@@ -570,7 +572,9 @@ def main():
                     tf = dm["issued"] / (dm["ms"] * 1e-3) / 1e12
                     gbs = dm["bytes"] / (dm["ms"] * 1e-3) / 1e9
                     alts[mode]["roofline"] = {
-                        "kernel": "flowse::conv3x3_halo16_kernel / conv3x3_halo_bf16_kernel (LDS-halo 3x3, 16-bit MFMA operands, fused GroupNorm+SiLU input)",
+                        "kernel": ("flowse::conv3x3_halo_bf16_kernel (fp32 storage, split-bf16 x3 operands, LDS halo)" if mode == "bf16x3" else
+                                   "flowse::conv3x3_pc16_kernel (+ conv3x3_halo_bf16_kernel on small launches): persistent "
+                                   "producer/consumer LDS-halo 3x3 conv, 16-bit MFMA operands, fused GroupNorm+SiLU input"),
                         "bound": "hbm" if gbs / HBM_PEAK_GBS > tf / PEAK_16BIT_MATRIX_TFLOPS else "mfma",
                         "achieved_TFLOPs_issued": tf, "mfma_peak_TFLOPs": PEAK_16BIT_MATRIX_TFLOPS,
                         "mfma_frac": tf / PEAK_16BIT_MATRIX_TFLOPS,

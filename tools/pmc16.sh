@@ -18,10 +18,9 @@ for d in sorted(glob.glob('gpurun_out/pmc16/*/')):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            if 'halo16' not in k and 'halo_bf16' not in k: continue
+            if 'pc16' not in k and 'halo_bf16' not in k: continue
             acc[(k[:60], r.get('Grid_Size', '?'))][r['Counter_Name']].append(float(r['Counter_Value']))
         for key, cs in sorted(acc.items()):
-            if key[1] != '1048576': continue
             for c, v in sorted(cs.items()):
                 print(os.path.basename(os.path.dirname(d)), key[0][:40], 'grid', key[1], c, 'n', len(v), 'mean %.5e' % (sum(v)/len(v)))
 PY
