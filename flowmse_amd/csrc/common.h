@@ -56,8 +56,10 @@ template <> struct St<bf16_t> {
                            __uint_as_float(r.y & 0xffff0000u));
     }
     static __device__ __forceinline__ unsigned pack2(float a, float b) {
-        const __bf16 x = (__bf16)a, y = (__bf16)b;                             // round to nearest even
-        return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+        // round to nearest even; ONE instruction (two scalar __bf16 casts lower to two conversions plus SDWA / v_bitop3 merges)
+        unsigned r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
     }
     static __device__ __forceinline__ void unpack2(unsigned w, float& a, float& b) {
         a = __uint_as_float(w << 16);
@@ -254,6 +256,7 @@ struct ConvArgs {
     const void* wq = nullptr;
     int terms = 0;
     int wq_f16 = 0;     // 1: the planes hold IEEE half instead of bf16 (terms must be 1; BASELINE config 5)
+    const void* wfrag = nullptr;   // the same 3x3 weights in MFMA fragment order (launch_pc16_weights): conv3x3_pc16_kernel's B operand
     // optional F(4,3) Winograd weights of a 3x3 conv in MFMA fragment order (launch_f43_weights): when set and the
     // shape qualifies (conv_supports_wino) the fp32 3x3 runs the Winograd kernel (18 transformed taps per channel pair)
     const float* wino = nullptr;
@@ -268,12 +271,15 @@ int conv16_ksplit(int B, int H, int W, int Cin, int Cout, int taps);
 // true when a 3x3 conv with 16-bit operands runs the LDS-halo kernel (fused GroupNorm input possible, statistics of the
 // output fused, H*W/128 partial blocks); otherwise the flat 16-bit kernel (+ split-K) takes it
 bool conv16_uses_halo(int B, int H, int W, int C1, int C2, int Cout, int taps);
+bool conv16_uses_pc(int B, int H, int W, int C1, int C2, int Cout, int taps);     // ... and the producer / consumer form of it (needs ConvArgs::wfrag)
 // number of per-sample partial-statistics blocks the 16-bit conv path writes for this shape (0 = none)
 int conv16_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps);
 // elementwise storage conversion (n elements, n % 4 == 0)
 int launch_convert(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, hipStream_t s);
 // F(4,3) Winograd weight transform along the kernel's vertical axis, packed [Cout][9][Cin] -> fragment order, on device
 int launch_f43_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s);
+// [Cout][9][Cin] 16-bit weights -> MFMA fragment order for conv3x3_pc16_kernel (same element count)
+int launch_pc16_weights(const void* w16, int Cout, int Cin, void* dst, hipStream_t s);
 inline int64_t conv_wino_numel(int Cout, int Cin) { return (int64_t)Cout * 18 * Cin; }
 bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // whole-K F(4,3) launches of this shape use 128-channel blocks (conv3x3_f43_kernel<GN, false, 2>)

@@ -51,11 +51,12 @@ namespace flowse {
 namespace {
 constexpr int PC_ROWB = 80;                        // bytes per halo pixel / weight row: 32 x 16 bit + 16 pad (conflict-free b128 reads)
 constexpr int PC_HPITCH = 18 * PC_ROWB + 96;       // halo image row: 1536 B = 0 mod 256
-constexpr int PC_HBUF_X = 32768;                   // pitch of the two halo buffers (18 rows = 27 KB each; a power of two: the offset toggles by XOR)
-constexpr int PC_WSLOT = 128 * PC_ROWB;            // one tap's weight tile (128 output channels x 32 channels)
+constexpr int PC_HBUF_X = 32768;                   // pitch of the three halo buffers (18 rows = 27 KB each)
+constexpr int PCF_STEP = 2 * 64 * 16;                // fragment-order weights: bytes of one (32-channel block, chunk, tap) = 2 halves x 1 KB
+constexpr int PCF_CHUNK = 9 * PCF_STEP;
 constexpr int PC_RED = 2 * 2 * 128 * 2 * 4;        // statistics scratch of the output stage: [2 waves][2 sub-tiles][128 ch][mean, M2]
 constexpr int PC_TSCR = 4 * 32 * 68 * 4;             // the consumers' transposition tiles (pc16_out_wide)
-constexpr int PC_LDS = 2 * PC_HBUF_X + 3 * PC_WSLOT + PC_RED + PC_TSCR;
+constexpr int PC_LDS = 3 * PC_HBUF_X + PC_RED + PC_TSCR;
 constexpr int PC_PIECES = 6;                       // 16-byte halo pieces per producer thread and chunk (324 x 4 / 256)
 
 // position of one (tile, channel block) work item
@@ -74,59 +75,58 @@ struct PcItem {
 // channel and 8 x 16 statistics tile) of exactly what was stored: per lane over its 8 pixels of a sub-tile (pivoted),
 // equal-count Chan merges over the 8 lanes that share a channel octet (64 pixels), then with the wave that holds the
 // other 64 pixels through `red` ([2][2][128][2] floats) after ONE block barrier -- which the producers match.
-// two fp32 -> one dword of two 16-bit values, round to nearest even.  bf16: ONE v_cvt_pk_bf16_f32 (hipcc lowers two
-// scalar __bf16 casts to two conversions plus a v_bitop3 merge -- 12 instead of 4 instructions per staged halo piece, and
-// every producer instruction costs 7-10 cycles next to the consumers' MFMA stream, tools/pc16_ts.py)
 template <bool F16>
 __device__ __forceinline__ unsigned pc_pack2(float a, float b) {
-    if constexpr (F16) {
-        return St<f16_t>::pack2(a, b);
-    } else {
-        unsigned r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-        return r;
-    }
+    return St<typename std::conditional<F16, f16_t, bf16_t>::type>::pack2(a, b);
 }
 
 constexpr int PCW_PITCH = 68;                              // floats per pixel row of the transposition tile (64 + 16 B)
-template <class OT>
+// RES: a residual is added (a uniform property of the launch; as a template parameter it costs no per-value selects).
+// Addressing: one per-lane byte offset per tile, every (t, i, k) increment is wave-uniform and travels in the buffer
+// instructions' scalar offset -- 64-bit per-pixel address arithmetic was ~250 of the stage's ~1 600 VALU instructions per
+// wave and tile, and VALU time adds to MFMA time on a SIMD.  Bias / residual / scale / statistics in packed fp32 pairs.
+// Where a tile's outputs (and residuals) live: per-sample buffer descriptors, one per-lane byte offset; every (t, i, k)
+// increment is wave-uniform (pc_osoff) and travels in the buffer instructions' scalar offset.
+struct PcOut {
+    __amdgpu_buffer_rsrc_t rs_out, rs_res;
+    unsigned voff;
+    int rowb, cstep;                                       // bytes per image row / per 8 pixels of a row
+};
+// pixel (pl + 8 k) of row pair (t, i): row = y0 + 8 t + 2 (2 wm + i) + (k >> 1), column = x0 + pl + 8 (k & 1)
+__device__ __forceinline__ unsigned pc_osoff(const PcOut& o, int t, int i, int k) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((8 * t + 2 * i + (k >> 1)) * o.rowb + (k & 1) * o.cstep);
+}
+// Residuals and the next tile's B-fragment ring share the ring's 48 registers (explicitly: left to the allocator, early
+// residual requests were spilled to scratch behind an s_waitcnt vmcnt(0)).  Round r = 2 t + i of the stage:
+//   residual of round 0 / 1 / 2 arrives in wb[0] / wb[1] / wb[2], requested by the caller after the tile's last MFMAs on that
+//   entry (taps 6 / 7 / 8 of its last chunk: three to one steps before the stage -- a round-ahead request left ~1 000 cycles
+//   of latency per round exposed: 9.7 k vs 5.4 k cycles per tile with and without a residual, tools/pc16_ts.py); round 3's
+//   goes into wb[0] when round 0 has consumed it;
+// The next tile's first three ring entries are requested by the caller AFTER the stage (requested from inside it, into the
+// registers of consumed residuals, they were spilled as well): ~700 cycles of L2 latency per tile stay exposed.
+template <class OT, bool RES>
 __device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2][2][2], float* T, float* red, int b, int y0,
-                                              int x0, int n0, int tiles_x) {
+                                              int x0, int n0, int tiles_x, bf16x8 (&wb)[3][2][2], const PcOut& po) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kh = lane >> 5;
     const int o = lane & 7, pl = lane >> 3;                // read side: channel octet, pixel lane (pixels pl + 8 k)
-    const int H = a.H, W = a.W, Cout = a.Cout;
+    const int Cout = a.Cout;
     const int ch0 = n0 + wn * 64 + o * 8;                  // this lane's 8 output channels
-    const OT* resp = reinterpret_cast<const OT*>(a.res);
-    OT* outp = reinterpret_cast<OT*>(a.out);
-    const bool has_res = resp != nullptr;
-    float bq[8];
+    f32x2 bq[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bq[e] = a.bias ? a.bias[ch0 + e] : 0.f;
+    for (int e = 0; e < 4; ++e) bq[e] = a.bias ? f32x2{a.bias[ch0 + 2 * e], a.bias[ch0 + 2 * e + 1]} : f32x2{0.f, 0.f};
     if (a.bias2) {
+        const float* b2 = a.bias2 + (int64_t)b * a.bias2_stride + ch0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bq[e] += a.bias2[(int64_t)b * a.bias2_stride + ch0 + e];
+        for (int e = 0; e < 4; ++e) bq[e] += f32x2{b2[2 * e], b2[2 * e + 1]};
     }
-    const float scale = a.scale;
-    // element offset of pixel (pl + 8 k) of row pair (t, i): row = y0 + 8 t + 2 (2 wm + i) + (p >> 4), p = pl + 8 k
-    auto pix_off = [&](int t, int i, int k) {
-        const int p = pl + 8 * k;
-        const int row = y0 + 8 * t + 2 * (2 * wm + i) + (p >> 4), col = x0 + (p & 15);
-        return ((int64_t)(b * H + row) * W + col) * Cout + ch0;
-    };
-    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-    u32x4v rres[4];
-    auto load_res = [&](int t, int i) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rres[k] = *reinterpret_cast<const u32x4v*>(resp + pix_off(t, i, k));
-    };
-    if (has_res) load_res(0, 0);
+    const f32x2 scale = {a.scale, a.scale};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        float piv[8], s1[8], s2[8];
+        f32x2 piv[4], s1[4], s2[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { piv[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { piv[e] = f32x2{0.f, 0.f}; s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             // accumulators -> T[pixel][channel]: register r of tile j = pixel (r & 3) + 8 (r >> 2) + 4 kh, channel 32 j + li
@@ -134,44 +134,47 @@ __device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kh) * PCW_PITCH + j * 32 + li] = acc[t][i][j][r];
-            u32x4v cur[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cur[k] = rres[k];
-            if (has_res && !(t == 1 && i == 1)) load_res(i == 1 ? t + 1 : t, i ^ 1);     // next row pair's residual in flight
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float4 lo = *reinterpret_cast<const float4*>(T + (pl + 8 * k) * PCW_PITCH + o * 8);
                 const float4 hi = *reinterpret_cast<const float4*>(T + (pl + 8 * k) * PCW_PITCH + o * 8 + 4);
-                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                const unsigned rw[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+                f32x2 v[4] = {f32x2{lo.x, lo.y}, f32x2{lo.z, lo.w}, f32x2{hi.x, hi.y}, f32x2{hi.z, hi.w}};
                 unsigned w[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float v0 = v[2 * q] + bq[2 * q], v1 = v[2 * q + 1] + bq[2 * q + 1];
-                    if (has_res) {
+                    f32x2 x = v[q] + bq[q];
+                    if (RES) {
+                        const u32x4 rr = __builtin_bit_cast(u32x4, wb[(2 * t + i) % 3][k >> 1][k & 1]);
+                        const unsigned rw = q == 0 ? rr.x : q == 1 ? rr.y : q == 2 ? rr.z : rr.w;
                         float r0, r1;
-                        St<OT>::unpack2(rw[q], r0, r1);
-                        v0 += r0;
-                        v1 += r1;
+                        St<OT>::unpack2(rw, r0, r1);
+                        x += f32x2{r0, r1};
                     }
-                    v0 *= scale;
-                    v1 *= scale;
-                    w[q] = St<OT>::pack2(v0, v1);
-                    St<OT>::unpack2(w[q], v0, v1);                         // statistics of what is stored
-                    if (i == 0 && k == 0) { piv[2 * q] = v0; piv[2 * q + 1] = v1; }
-                    const float d0 = v0 - piv[2 * q], d1 = v1 - piv[2 * q + 1];
-                    s1[2 * q] += d0; s2[2 * q] = fmaf(d0, d0, s2[2 * q]);
-                    s1[2 * q + 1] += d1; s2[2 * q + 1] = fmaf(d1, d1, s2[2 * q + 1]);
+                    x *= scale;
+                    w[q] = St<OT>::pack2(x.x, x.y);
+                    float u0, u1;
+                    St<OT>::unpack2(w[q], u0, u1);                         // statistics of what is stored
+                    const f32x2 u = {u0, u1};
+                    if (i == 0 && k == 0) piv[q] = u;
+                    const f32x2 d = u - piv[q];
+                    s1[q] += d;
+                    s2[q] = __builtin_elementwise_fma(d, d, s2[q]);
                 }
-                *reinterpret_cast<u32x4v*>(outp + pix_off(t, i, k)) = u32x4v{w[0], w[1], w[2], w[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, po.rs_out, po.voff, pc_osoff(po, t, i, k), 0);
+                if (RES && t == 0 && i == 0)                // round 3's residual into the registers round 0 just read
+                    wb[0][k >> 1][k & 1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        po.rs_res, po.voff, pc_osoff(po, 1, 1, k), 0));
             }
         }
         if (!a.stats) continue;
         // 8 values per lane and channel -> the 8 pixel lanes of the octet (64 = this wave's pixels of sub-tile t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float mean = piv[e] + s1[e] * 0.125f;
-            float m2 = fmaxf(s2[e] - s1[e] * s1[e] * 0.125f, 0.f);
+            const float pv = (e & 1) ? piv[e >> 1].y : piv[e >> 1].x;
+            const float a1 = (e & 1) ? s1[e >> 1].y : s1[e >> 1].x;
+            const float a2 = (e & 1) ? s2[e >> 1].y : s2[e >> 1].x;
+            float mean = pv + a1 * 0.125f;
+            float m2 = fmaxf(a2 - a1 * a1 * 0.125f, 0.f);
             float cnt = 8.f;
 #pragma unroll
             for (int off = 8; off < 64; off <<= 1) {
@@ -188,7 +191,7 @@ __device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2
             }
         }
     }
-    __syncthreads();                                       // (S) always: the producers' hand-over point as well
+    __syncthreads();                                       // (S) always: the producers match it
     if (!a.stats) return;
     if (tid < 128) {
         const int tile0 = (y0 >> 3) * tiles_x + (x0 >> 4);
@@ -208,9 +211,8 @@ template <int GN, bool F16>
 __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     using T16 = typename std::conditional<F16, f16_t, bf16_t>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* Hs = reinterpret_cast<char*>(smem);              // [2][18][PC_HPITCH] at a pitch of PC_HBUF_X
-    char* Ws = Hs + 2 * PC_HBUF_X;                         // [3][128][PC_ROWB]
-    float* red = reinterpret_cast<float*>(Ws + 3 * PC_WSLOT);
+    char* Hs = reinterpret_cast<char*>(smem);              // [3][18][PC_HPITCH] at a pitch of PC_HBUF_X
+    float* red = reinterpret_cast<float*>(Hs + 3 * PC_HBUF_X);
     float* tscr = red + PC_RED / 4;                        // [4 consumer waves][32][PCW_PITCH]
 
     const int tid = threadIdx.x;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     };
 
     if (wave < 4) {
-        // =============================================================================== consumers: fragments + MFMA
+        // ====================================================== consumers: A fragments from LDS, B fragments from L2, MFMA
         const int lane = tid & 63;
         const int wm = wave >> 1, wn = wave & 1;
         const int li = lane & 31, kh = lane >> 5;
@@ -255,7 +257,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
             const int py = 2 * (wm * 2 + i) + (li >> 4), px = li & 15;
             abase[i] = (py + 1) * PC_HPITCH + (px + 1) * PC_ROWB + kh * 16;
         }
-        const int bbase = (wn * 64 + li) * PC_ROWB + kh * 16;
+        // weights in fragment order (pc16_weights_kernel): one buffer_load_b128 per wave = one MFMA B operand, 1 KB contiguous
+        const __amdgpu_buffer_rsrc_t rsrcw =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wfrag), 0, a.Cout * 9 * Cin * 2, 0x00020000);
+        const unsigned bvo = (unsigned)lane * 16u;
+        const unsigned jstride = (unsigned)nchunks * PCF_CHUNK;   // bytes between two 32-channel blocks
+        auto wsoff = [&](int g) {                          // byte offset of (32-channel block wn * 2, chunk) of stream chunk g
+            g = min(g, Ctot - 1);
+            const int k = g / nchunks;
+            const PcItem p = item_at(k);
+            return (unsigned)__builtin_amdgcn_readfirstlane((((p.n0 >> 5) + wn * 2) * nchunks + (g - k * nchunks)) * PCF_CHUNK);
+        };
         f32x16 acc[2][2][2];
         auto zero_acc = [&]() {
 #pragma unroll
@@ -268,21 +280,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
                         for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
         };
         zero_acc();
-        // A step = two half-steps of 16 channels (mh = 0, 1), 8 MFMAs each.  The fragments of half-step h + 1 are requested
-        // before the MFMAs of half-step h: two sets of 6 fragments (48 registers), not two whole steps' worth.
-        bf16x8 xa[2][2], xb[2], ya[2][2], yb[2];             // [t][i], [j]
+        // A step = two half-steps of 16 channels (mh = 0, 1), 8 MFMAs each.  The A fragments of half-step h + 1 are requested
+        // before the MFMAs of half-step h (two sets of 4); the B fragments of a whole step travel through a ring of three
+        // register sets, i.e. they are requested three steps (>= 1 500 cycles) before their MFMAs.
+        bf16x8 xa[2][2], ya[2][2];                         // [t][i]
+        bf16x8 wb[3][2][2];                                // [ring][mh][j]
 
-        // fragments of half-step (halo buffer offset HOFF, weight slot SL, tap TAP, half MH) into set (FA, FB)
-#define FLOWSE_PC_LOADF(FA, FB, HOFF, SL, TAP, MH)                                                                   \
+#define FLOWSE_PC_LOADA(FA, HOFF, TAP, MH)                                                                           \
     {                                                                                                                \
         constexpr int tapoff = ((TAP) / 3 - 1) * PC_HPITCH + ((TAP) % 3 - 1) * PC_ROWB + (MH) * 32;                  \
         const char* Hb = Hs + (HOFF) + tapoff;                                                                       \
-        const char* Wb = Ws + (SL) * PC_WSLOT + bbase + (MH) * 32;                                                   \
         _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i)                  \
             FA[t][i] = *reinterpret_cast<const bf16x8*>(Hb + abase[i] + t * 8 * PC_HPITCH);                          \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
-            FB[j] = *reinterpret_cast<const bf16x8*>(Wb + j * 32 * PC_ROWB);                                         \
     }
+#define FLOWSE_PC_WLOAD(RING, SOFF, TAPV)                                                                            \
+    _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) _Pragma("unroll") for (int j = 0; j < 2; ++j)                   \
+        wb[RING][mh][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                          \
+            rsrcw, bvo, (SOFF) + (unsigned)j * jstride + (unsigned)((TAPV) * PCF_STEP + mh * 1024), 0));
 #define FLOWSE_PC_MMA(FA, FB)                                                                                        \
     _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i)                      \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
@@ -292,63 +306,92 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         else                                                                                                         \
             acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[t][i], FB[j], acc[t][i][j], 0, 0, 0);          \
     }
-        int cit = 0;                                       // chunk inside the current tile
-        int kitem = 0;                                     // ordinal of the current item
-        // One step at tap TAP of the current chunk (halo buffer offset hoff, weight slot TAP % 3).  Entering, set X holds
-        // the fragments of (TAP, mh 0); leaving, those of the next step's mh 0.
+        // One step at tap TAP of the current chunk (halo buffer offset hoff, B ring entry TAP % 3).  Entering, set X holds the
+        // A fragments of (TAP, mh 0); leaving, those of the next step's mh 0 (across a chunk boundary too: the next chunk's halo
+        // is complete since the barrier of THIS chunk).  The ring entry is refilled with step + 3.  In a tile's last chunk
+        // nothing of the next tile is requested (its ring comes from inside the output stage, its first A fragments after
+        // it); the ring registers freed at taps 6 and 7 take the residuals of the output stage's first two rounds.
 #define FLOWSE_PC_STEP(TAP)                                                                                          \
     {                                                                                                                \
-        FLOWSE_PC_LOADF(ya, yb, hoff, (TAP) % 3, (TAP), 1)                                                           \
+        FLOWSE_PC_LOADA(ya, hoff, (TAP), 1)                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        FLOWSE_PC_MMA(xa, xb)                                                                                        \
+        FLOWSE_PC_MMA(xa, wb[(TAP) % 3][0])                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if constexpr ((TAP) < 8) {                                                                                   \
-            FLOWSE_PC_LOADF(xa, xb, hoff, ((TAP) + 1) % 3, ((TAP) + 1) % 9, 0)                                       \
-        } else if (!tile_end) {                            /* (a tile's first fragments: after its halo burst) */  \
-            FLOWSE_PC_LOADF(xa, xb, hoff ^ PC_HBUF_X, 0, 0, 0)                                                       \
-        }                                                                                                            \
+        if constexpr ((TAP) < 8) { FLOWSE_PC_LOADA(xa, hoff, ((TAP) + 1) % 9, 0) }                                   \
+        else if (!tile_end) { FLOWSE_PC_LOADA(xa, hnext, 0, 0) }                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        FLOWSE_PC_MMA(ya, yb)                                                                                        \
+        FLOWSE_PC_MMA(ya, wb[(TAP) % 3][1])                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        PC_TS_ADD(0)                                       /* 0: fragments + MFMA issue */                          \
-        __syncthreads();                                                                                             \
-        PC_TS_ADD(1)                                       /* 1: step barrier */                                    \
+        if constexpr ((TAP) + 3 < 9) { FLOWSE_PC_WLOAD((TAP) % 3, wcur, (TAP) + 3) }                                 \
+        else if (!tile_end) { FLOWSE_PC_WLOAD((TAP) % 3, wnext, (TAP) + 3 - 9) }                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+#define FLOWSE_PC_RESLOAD(R)                               /* residual of output round R into ring entry R (see pc16_out_wide) */ \
+    if (tile_end && has_res) {                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                \
+            wb[R][k >> 1][k & 1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                 \
+                po.rs_res, po.voff, pc_osoff(po, (R) >> 1, (R) & 1, k), 0));                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
         PC_TS_DECL
         PC_TS_START
-        __syncthreads();                                   // (A) halo of chunk 0 and the weight tiles of steps 0, 1 are in LDS
-        PC_TS_ADD(2)                                       // 2: prologue wait
-        int hoff = 0;                                      // byte offset of the current chunk's halo buffer: 0 / PC_HBUF_X
-        FLOWSE_PC_LOADF(xa, xb, hoff, 0, 0, 0)
+        int cit = 0;                                       // chunk inside the current tile
+        int kitem = 0;                                     // ordinal of the current item
+        const bool has_res = a.res != nullptr;
+        PcItem pit = item_at(0);
+        PcOut po;
+        po.rowb = W * a.Cout * 2;
+        po.cstep = 16 * a.Cout;
+        auto set_out = [&]() {                             // descriptors and lane offset of tile `pit`
+            const int64_t sb = (int64_t)pit.b * H * W * a.Cout;
+            T16* ob = reinterpret_cast<T16*>(a.out) + sb;
+            const T16* rb = has_res ? reinterpret_cast<const T16*>(a.res) + sb : ob;
+            po.rs_out = __builtin_amdgcn_make_buffer_rsrc(ob, 0, H * po.rowb, 0x00020000);
+            po.rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<T16*>(rb), 0, H * po.rowb, 0x00020000);
+            po.voff = (unsigned)((((pit.y0 + 4 * wm) * W + pit.x0 + (lane >> 3)) * a.Cout + pit.n0 + wn * 64 + (lane & 7) * 8) * 2);
+        };
+        set_out();
+        int hoff = 0;                                      // byte offset of the current chunk's halo buffer
+        unsigned wcur = wsoff(0), wnext = wsoff(1);
+        FLOWSE_PC_WLOAD(0, wcur, 0) FLOWSE_PC_WLOAD(1, wcur, 1) FLOWSE_PC_WLOAD(2, wcur, 2)
+        __syncthreads();                                   // (X 0)
+        FLOWSE_PC_LOADA(xa, 0, 0, 0)
         for (int gc = 0; gc < Ctot; ++gc) {
             const bool tile_end = cit == nchunks - 1;
-            if (!tile_end) {                               // (T) the producers normalise the next chunk's halo in one burst while
-                __syncthreads();                           //     no MFMA is in flight on their SIMDs (see the header)
-                PC_TS_ADD(4)                               // 4: waiting for the halo burst
-            }
-            FLOWSE_PC_STEP(0) FLOWSE_PC_STEP(1) FLOWSE_PC_STEP(2) FLOWSE_PC_STEP(3) FLOWSE_PC_STEP(4)
-            FLOWSE_PC_STEP(5) FLOWSE_PC_STEP(6) FLOWSE_PC_STEP(7) FLOWSE_PC_STEP(8)
-            hoff ^= PC_HBUF_X;
+            const int hnext = hoff == 2 * PC_HBUF_X ? 0 : hoff + PC_HBUF_X;
+            if (gc > 0) __syncthreads();                   // (X gc) the halos of chunks gc and gc + 1 are in LDS; the producers may
+            PC_TS_ADD(1)                                   //        overwrite the buffer of chunk gc - 1.   1: chunk barrier
+            FLOWSE_PC_STEP(0) FLOWSE_PC_STEP(1) FLOWSE_PC_STEP(2) FLOWSE_PC_STEP(3) FLOWSE_PC_STEP(4) FLOWSE_PC_STEP(5)
+            FLOWSE_PC_STEP(6) FLOWSE_PC_RESLOAD(0) FLOWSE_PC_STEP(7) FLOWSE_PC_RESLOAD(1) FLOWSE_PC_STEP(8) FLOWSE_PC_RESLOAD(2)
+            PC_TS_ADD(0)                                   // 0: fragments + MFMA issue
             ++cit;
-            if (tile_end) {                                // the tile is complete: output stage, next tile
-                const PcItem p = item_at(kitem);
-                // (its block barrier (S) is also where the producers hand over the next tile's first halo)
-                pc16_out_wide<T16>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x);
+            if (tile_end) {                                // the tile is complete: output stage (its block barrier (S) is matched
+                const PcItem p = pit;                      // by the producers), next tile
+                if (has_res) pc16_out_wide<T16, true>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x, wb, po);
+                else pc16_out_wide<T16, false>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x, wb, po);
                 zero_acc();
                 cit = 0;
                 ++kitem;
+                pit = item_at(min(kitem, n_items - 1));
+                set_out();
                 PC_TS_ADD(3)                               // 3: output stage
-                if (gc + 1 < Ctot) { FLOWSE_PC_LOADF(xa, xb, hoff, 0, 0, 0) }
+                FLOWSE_PC_WLOAD(0, wnext, 0) FLOWSE_PC_WLOAD(1, wnext, 1) FLOWSE_PC_WLOAD(2, wnext, 2)
+                FLOWSE_PC_LOADA(xa, hnext, 0, 0)           // (in LDS since the barrier of the finished chunk; a stale read after the last tile is never used)
             }
+            hoff = hnext;
+            wcur = wnext;
+            wnext = wsoff(gc + 2);
         }
         if (wave == 0) { PC_TS_FLUSH(0) }                  // slots 0-7 of the block
+#undef FLOWSE_PC_RESLOAD
 #undef FLOWSE_PC_STEP
 #undef FLOWSE_PC_MMA
-#undef FLOWSE_PC_LOADF
+#undef FLOWSE_PC_WLOAD
+#undef FLOWSE_PC_LOADA
         return;
     }
 
-    // =================================================================================== producers: staging
+    // =================================================================================== producers: halo staging
     const int ltid = tid - 256;
     const int octet = ltid & 3;                            // this thread's 8-channel group inside a 32-channel chunk
     const int hp0 = ltid >> 2;                             // halo pixels hp0 + 64 q
@@ -363,8 +406,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         if (q & 1) hyx[q >> 1] |= pk << 16; else hyx[q >> 1] = pk;
     }
     const bool last_valid = hp0 + 64 * (PC_PIECES - 1) < 324;      // piece 5 exists for 16 threads only
-    int hlds[PC_PIECES];                                   // LDS byte offset of each piece inside a halo buffer (plain registers:
-#pragma unroll                                             // the kernel's allocation is set by the consumers, the producers have room)
+    int hlds[PC_PIECES];                                   // LDS byte offset of each piece inside a halo buffer
+#pragma unroll
     for (int q = 0; q < PC_PIECES; ++q) {
         const int hp = hp0 + 64 * q;
         const int hy = hp / 18, hx = hp - hy * 18;
@@ -372,10 +415,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     }
     auto h_y = [&](int q) { return (hyx[q >> 1] >> ((q & 1) * 16)) & 0xffu; };
     auto h_x = [&](int q) { return (hyx[q >> 1] >> ((q & 1) * 16 + 8)) & 0xffu; };
-    const int bcol = ltid & 3, brow0 = ltid >> 2;          // weight staging: 16-byte column, rows brow0 + 64 q
-    const unsigned bvo0 = (unsigned)(brow0 * 9 * Cin * 2 + bcol * 16), bvo_step = (unsigned)(64 * 9 * Cin * 2);
-    const __amdgpu_buffer_rsrc_t rsrcw =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wq), 0, a.Cout * 9 * Cin * 2, 0x00020000);
     const T16* in1p = reinterpret_cast<const T16*>(a.in1);
     const T16* in2p = reinterpret_cast<const T16*>(a.in2);
     const int wpix = 17 * W + 18;
@@ -441,15 +480,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
             shv[2 * h + 1] = f32x2{fmaf(-m4.z, s4.z, b4.z), fmaf(-m4.w, s4.w, b4.w)};
         }
     };
-    // The halo of chunk + 1 (raw pieces in RX, parameters (SCX, SHX)) is normalised in ONE burst into buffer HB, at a moment
-    // when the consumers issue no MFMA: next to a saturated MFMA stream every VALU instruction of the co-resident wave costs
-    // 7-10 cycles (tools/pc16_ts.py: 290 cycles per piece, 1 000-cycle steps against 512 cycles of MFMA), alone on the SIMD
-    // 2-4.  Paying ~900 cycles once per chunk beats ~3 000 spread under the MFMAs.
+    // The raw pieces RX (parameters (SCX, SHX)) of one chunk are normalised into the halo buffer at byte offset HB, stage by
+    // stage over ALL pieces (24 channel pairs): a lone wave hides no latency by itself -- piece after piece the dependent
+    // unpack -> fma -> exp -> rcp -> mul chains ran at ~10 cycles per instruction, 24 independent pairs per stage keep the
+    // VALU issuing (2 900 vs 3 300 cycles per chunk, tools/pc16_ts.py).
 #define FLOWSE_PC_BURST(RX, HINX, SCX, SHX, HB)                                                                      \
     if (GN) {                                                                                                        \
-        /* stage by stage over ALL pieces (24 channel pairs): a lone wave hides no latency by itself -- piece after piece   \
-           the dependent unpack -> fma -> exp -> rcp -> mul chains ran at ~10 cycles per instruction (3 300 cycles per      \
-           burst, tools/pc16_ts.py); 24 independent pairs per stage keep the VALU issuing */                               \
         f32x2 v[PC_PIECES][4], z[PC_PIECES][4];                                                                      \
         _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
             const unsigned wsrc[4] = {RX[q].x, RX[q].y, RX[q].z, RX[q].w};                                           \
@@ -485,109 +521,99 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
             t.y = pc_pack2<F16>(v[q][1].x, v[q][1].y) & keepm;                                                       \
             t.z = pc_pack2<F16>(v[q][2].x, v[q][2].y) & keepm;                                                       \
             t.w = pc_pack2<F16>(v[q][3].x, v[q][3].y) & keepm;                                                       \
-            if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) * PC_HBUF_X + hlds[q]) = t;     \
+            if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) + hlds[q]) = t;                 \
         }                                                                                                            \
     } else {                                                                                                         \
         _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q)                                                        \
-            if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) * PC_HBUF_X + hlds[q]) = RX[q]; \
+            if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) + hlds[q]) = RX[q];             \
     }
-    // weight tile of (cursor CURV, tap TAPV): [128 output channels][32 channels], two 16-byte columns per thread.  The tiles
-    // travel through a ring of NINE register sets, i.e. they are requested a whole chunk (nine steps) before they are written to
-    // LDS: vector memory loads return in issue order, so a weight tile (an L2 hit) requested behind the halo pieces of the next
-    // chunk (first touch of those pixels: HBM, 2-4 us under load) is only visible once they have landed -- with a three-step
-    // ring the producers sat in s_waitcnt for ~300 cycles per step (tools/pc16_ts.py); nine steps outlast the HBM round trip.
-    u32x4 wr[9][2];
-#define FLOWSE_PC_WLOAD(RING, CURV, TAPV)                                                                            \
-    {                                                                                                                \
-        const Cur& cc = (CURV);                                                                                      \
-        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(                                              \
-            ((cc.p.n0 * 9 + (TAPV)) * Cin + cc.chunk * KC) * 2);                                                     \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                \
-            wr[RING][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, bvo0 + q * bvo_step, soff, 0);                \
-    }
-#define FLOWSE_PC_WSTORE(RING, SL)                                                                                   \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                    \
-        *reinterpret_cast<u32x4*>(Ws + (SL) * PC_WSLOT + (brow0 + 64 * q) * PC_ROWB + bcol * 16) = wr[RING][q];
 
-    // ---- prologue: halo of chunk 0 -> buffer 0; weight tiles of steps 0, 1 -> slots 0, 1; ring <- steps 2 .. 10;
-    // rb <- raw halo of chunk 1 (normalised during chunk 0)
-    const Cur c0 = cursor(0);
-    Cur c1 = cursor(1), c2 = cursor(2);                    // cursors of the chunks gc + 1, gc + 2
-    FLOWSE_PC_HLOAD(ra, hin_a, c0)
-    load_params(c0, sca, sha);
-    FLOWSE_PC_WLOAD(0, c0, 0)
-    FLOWSE_PC_WLOAD(1, c0, 1)
-    FLOWSE_PC_HLOAD(rb, hin_b, c1)
-    FLOWSE_PC_BURST(ra, hin_a, sca, sha, 0)
-    FLOWSE_PC_WSTORE(0, 0)
-    FLOWSE_PC_WSTORE(1, 1)
-    FLOWSE_PC_WLOAD(2, c0, 2) FLOWSE_PC_WLOAD(3, c0, 3) FLOWSE_PC_WLOAD(4, c0, 4) FLOWSE_PC_WLOAD(5, c0, 5)
-    FLOWSE_PC_WLOAD(6, c0, 6) FLOWSE_PC_WLOAD(7, c0, 7) FLOWSE_PC_WLOAD(8, c0, 8)
-    FLOWSE_PC_WLOAD(0, c1, 0) FLOWSE_PC_WLOAD(1, c1, 1)
-    load_params(c1, scb, shb);
+    // ---- prologue: chunks 0 and 1 -> buffers 0 and 1; raw pieces of chunks 2 and 3 in flight
+    {
+        const Cur c0 = cursor(0), c1 = cursor(1), c2 = cursor(2), c3 = cursor(3);
+        FLOWSE_PC_HLOAD(ra, hin_a, c0)
+        load_params(c0, sca, sha);
+        FLOWSE_PC_HLOAD(rb, hin_b, c1)
+        load_params(c1, scb, shb);
+        FLOWSE_PC_BURST(ra, hin_a, sca, sha, 0)
+        FLOWSE_PC_HLOAD(ra, hin_a, c2)
+        load_params(c2, sca, sha);
+        FLOWSE_PC_BURST(rb, hin_b, scb, shb, PC_HBUF_X)
+        FLOWSE_PC_HLOAD(rb, hin_b, c3)
+        load_params(c3, scb, shb);
+    }
     PC_TS_DECL
     PC_TS_START
-    __syncthreads();                                       // (A)
-    PC_TS_ADD(2)
-
     int cit = 0;
-    // One producer step at (chunk gc + GO, tap TAP): weights only -- write tile s + 2 (ring entry (TAP + 2) % 9) into LDS slot
-    // (TAP + 2) % 3, request tile s + 11 into the same entry; tap 0 also requests the raw halo of chunk + 2 into RY, tap 6 the
-    // GroupNorm parameters of chunk + 2 into (SCY, SHY).  CG1 / CG2: cursors of chunks gc + GO + 1, + 2.
-#define FLOWSE_PC_LSTEP(TAP, RY, HINY, SCY, SHY, CG1, CG2)                                                           \
-    {                                                                                                                \
-        constexpr int ring = ((TAP) + 2) % 9;              /* ring entry of step s + 2; its LDS slot is ring % 3 */ \
-        FLOWSE_PC_WSTORE(ring, ring % 3)                                                                             \
-        if constexpr ((TAP) + 2 < 9) { FLOWSE_PC_WLOAD(ring, CG1, (TAP) + 2) } else { FLOWSE_PC_WLOAD(ring, CG2, (TAP) + 2 - 9) } \
-        if constexpr ((TAP) == 0) { FLOWSE_PC_HLOAD(RY, HINY, CG2) }                                                 \
-        if constexpr ((TAP) == 6) load_params(CG2, SCY, SHY);                                                        \
-        PC_TS_ADD(0)                                       /* 0: producer work */                                   \
-        __syncthreads();                                                                                             \
-        PC_TS_ADD(1)                                       /* 1: producer at the step barrier */                    \
-    }
-    // One chunk: burst (T) for the next chunk of the same tile first; nine weight steps; at a tile's last chunk the burst for
-    // the NEXT tile's first chunk runs behind the steps, under the consumers' output stage, and ends at its barrier (S).
-#define FLOWSE_PC_LCHUNK(GO, RX, HINX, SCX, SHX, RY, HINY, SCY, SHY, CG1, CG2)                                       \
+    int hb = 2 * PC_HBUF_X;                                // buffer (byte offset) of chunk gc + 2
+    // One chunk interval gc + GO: after the chunk barrier the consumers work on chunk gc + GO and are done with chunk
+    // gc + GO - 1, whose buffer takes chunk gc + GO + 2 (raw pieces RX, requested two intervals ago); then the raw pieces
+    // of chunk gc + GO + 4 are requested into the same registers.  The staging runs a whole chunk ahead of what the next
+    // barrier needs, so the consumers never wait for it unless the producers fall a chunk behind (output stage: the bursts
+    // of the next tile's first two chunks are done before the tile's barrier (S)).
+#define FLOWSE_PC_LCHUNK(GO, RX, HINX, SCX, SHX)                                                                     \
     {                                                                                                                \
         const bool tile_end = cit == nchunks - 1;                                                                    \
-        if (!tile_end) {                                                                                             \
-            FLOWSE_PC_BURST(RX, HINX, SCX, SHX, ((GO) + 1) & 1)                                                      \
-            PC_TS_ADD(4)                                   /* 4: halo burst */                                      \
-            __syncthreads();                               /* (T) */                                                \
-            PC_TS_ADD(1)                                                                                             \
+        __syncthreads();                                   /* (X gc + GO) */                                        \
+        PC_TS_ADD(1)                                       /* 1: chunk barrier */                                   \
+        if (gc + (GO) + 2 < Ctot) { FLOWSE_PC_BURST(RX, HINX, SCX, SHX, hb) }                                        \
+        hb = hb == 2 * PC_HBUF_X ? 0 : hb + PC_HBUF_X;                                                               \
+        PC_TS_ADD(4)                                       /* 4: halo burst */                                      \
+        {                                                                                                            \
+            const Cur c4 = cursor(gc + (GO) + 4);                                                                    \
+            FLOWSE_PC_HLOAD(RX, HINX, c4)                                                                            \
+            load_params(c4, SCX, SHX);                                                                               \
         }                                                                                                            \
-        FLOWSE_PC_LSTEP(0, RY, HINY, SCY, SHY, CG1, CG2) FLOWSE_PC_LSTEP(1, RY, HINY, SCY, SHY, CG1, CG2)            \
-        FLOWSE_PC_LSTEP(2, RY, HINY, SCY, SHY, CG1, CG2) FLOWSE_PC_LSTEP(3, RY, HINY, SCY, SHY, CG1, CG2)            \
-        FLOWSE_PC_LSTEP(4, RY, HINY, SCY, SHY, CG1, CG2) FLOWSE_PC_LSTEP(5, RY, HINY, SCY, SHY, CG1, CG2)            \
-        FLOWSE_PC_LSTEP(6, RY, HINY, SCY, SHY, CG1, CG2) FLOWSE_PC_LSTEP(7, RY, HINY, SCY, SHY, CG1, CG2)            \
-        FLOWSE_PC_LSTEP(8, RY, HINY, SCY, SHY, CG1, CG2)                                                             \
+        PC_TS_ADD(0)                                       /* 0: requests */                                        \
         ++cit;                                                                                                       \
         if (tile_end) {                                                                                              \
             cit = 0;                                                                                                 \
-            if (gc + (GO) + 1 < Ctot) { FLOWSE_PC_BURST(RX, HINX, SCX, SHX, ((GO) + 1) & 1) }                        \
-            PC_TS_ADD(4)                                                                                             \
             __syncthreads();                               /* (S) the consumers' output-stage barrier */            \
             PC_TS_ADD(3)                                   /* 3: waiting for the consumers' output stage */         \
         }                                                                                                            \
     }
     for (int gc = 0; gc < Ctot; gc += 2) {
-        // chunk gc: normalises rb (chunk gc + 1, parameters b), requests chunk gc + 2 into ra / a
-        FLOWSE_PC_LCHUNK(0, rb, hin_b, scb, shb, ra, hin_a, sca, sha, c1, c2)
-        if (gc + 1 < Ctot) {
-            const Cur c3 = cursor(gc + 3);
-            // chunk gc + 1: normalises ra (chunk gc + 2, parameters a), requests chunk gc + 3 into rb / b
-            FLOWSE_PC_LCHUNK(1, ra, hin_a, sca, sha, rb, hin_b, scb, shb, c2, c3)
-            c1 = c3;
-            c2 = cursor(gc + 4);
-        }
+        FLOWSE_PC_LCHUNK(0, ra, hin_a, sca, sha)           // ra holds chunk gc + 2
+        if (gc + 1 < Ctot) { FLOWSE_PC_LCHUNK(1, rb, hin_b, scb, shb) }       // rb holds chunk gc + 3
     }
 #undef FLOWSE_PC_LCHUNK
 #undef FLOWSE_PC_BURST
     if (wave == 4) { PC_TS_FLUSH(8) }                      // slots 8-15 of the block
-#undef FLOWSE_PC_LSTEP
-#undef FLOWSE_PC_WSTORE
-#undef FLOWSE_PC_WLOAD
 #undef FLOWSE_PC_HLOAD
+}
+
+// Weights of a 3x3 conv in MFMA fragment order for the consumers of conv3x3_pc16_kernel:
+//   dst[nb][chunk][tap][mh][lane = kh * 32 + li][8] = w[nb * 32 + li][tap][chunk * 32 + mh * 16 + kh * 8 + 0..7]
+// (w = [Cout][9][Cin] in the 16-bit operand type), i.e. one 1 KB line per wave-level B operand of v_mfma_f32_32x32x16.
+__global__ __launch_bounds__(256) void pc16_weights_kernel(const uint16_t* __restrict__ w, int Cout, int Cin,
+                                                          uint16_t* __restrict__ dst) {
+    const int nchunks = Cin / KC;
+    const int64_t n16 = (int64_t)Cout * 9 * Cin / 8;       // 16-byte units
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n16) return;
+    const int lane = (int)(u & 63);
+    int64_t r = u >> 6;
+    const int mh = (int)(r & 1);
+    r >>= 1;
+    const int tap = (int)(r % 9);
+    r /= 9;
+    const int chunk = (int)(r % nchunks);
+    const int nb = (int)(r / nchunks);
+    const int li = lane & 31, kh = lane >> 5;
+    const uint16_t* src = w + ((int64_t)(nb * 32 + li) * 9 + tap) * Cin + chunk * KC + mh * 16 + kh * 8;
+    *reinterpret_cast<uint4*>(dst + u * 8) = *reinterpret_cast<const uint4*>(src);
+}
+
+int launch_pc16_weights(const void* w16, int Cout, int Cin, void* dst, hipStream_t s) {
+    if ((Cin % KC) || (Cout % 32) || (int64_t)Cout * 9 * Cin * 2 >= (1LL << 31)) {
+        set_error("pc16_weights: unsupported Cout=%d Cin=%d", Cout, Cin);
+        return ERR_SHAPE;
+    }
+    const int64_t n16 = (int64_t)Cout * 9 * Cin / 8;
+    hipLaunchKernelGGL(pc16_weights_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const uint16_t*>(w16), Cout, Cin, static_cast<uint16_t*>(dst));
+    FLOWSE_LAUNCH_CHECK();
+    return OK;
 }
 
 // The producer / consumer form takes a 3x3 on 16-bit activations when its 16 x 16-pixel tiling applies and the launch
@@ -595,14 +621,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
 bool conv16_uses_pc(int B, int H, int W, int C1, int C2, int Cout, int taps) {
     if (taps != 9 || (H & 15) || (W & 15) || (C1 % KC) || (C2 % KC) || (Cout % 128)) return false;
     const int64_t cmax = C1 > C2 ? C1 : C2;
-    if ((int64_t)(17 * W + 18) * cmax * 2 >= (1LL << 31) || (int64_t)Cout * 9 * (C1 + C2) * 2 >= (1LL << 31)) return false;
+    if ((int64_t)(17 * W + 18) * cmax * 2 >= (1LL << 31) || (int64_t)Cout * 9 * (C1 + C2) * 2 >= (1LL << 31) ||
+        (int64_t)H * W * Cout * 2 >= (1LL << 31)) return false;
     return ((int64_t)B * H * W / 256) * (Cout / 128) >= 256;
 }
 
 int launch_pc16(const ConvArgs& a, hipStream_t s) {
-    if (a.in_dt == DT_F32 || a.in_dt != a.out_dt || a.terms != 1 || a.partial || !a.wq ||
+    if (a.in_dt == DT_F32 || a.in_dt != a.out_dt || a.terms != 1 || a.partial || !a.wq || !a.wfrag ||
         (a.wq_f16 ? DT_F16 : DT_BF16) != a.in_dt || !conv16_uses_pc(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
-        set_error("pc16: 16-bit storage in = out = operand type, 16 x 16-pixel tiles, no split-K form");
+        set_error("pc16: 16-bit storage in = out = operand type, fragment-order weights, 16 x 16-pixel tiles, no split-K form");
         return ERR_ARG;
     }
     int dev = 0, cus = 256;

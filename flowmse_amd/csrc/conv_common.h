@@ -30,7 +30,6 @@ int launch_halo_bf16x3(const ConvArgs& a, hipStream_t s);      // conv16.hip: sp
 int launch_halo16_any(const ConvArgs& a, hipStream_t s);       // conv16.hip: 16-bit operands, LDS-halo 3x3
 int launch_flat16(const ConvArgs& a, hipStream_t s);           // conv16.hip: 16-bit storage, flat 1x1 / small 3x3
 int launch_pc16(const ConvArgs& a, hipStream_t s);             // conv16_pc.hip: 16-bit storage, producer / consumer LDS-halo 3x3
-bool conv16_uses_pc(int B, int H, int W, int C1, int C2, int Cout, int taps);
 
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with its own
 // L2); remapping so that every XCD walks a CONTIGUOUS range of tiles keeps the rows shared by vertically

@@ -119,7 +119,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
             conv_supports_head4(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))
             return launch_head4(a, s);
         if (a.ksplit <= 1 && a.out_dt == a.in_dt && conv16_uses_halo(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
-            if (conv16_uses_pc(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) return launch_pc16(a, s);
+            if (a.wfrag && conv16_uses_pc(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) return launch_pc16(a, s);
             return launch_halo16_any(a, s);
         }
         if (a.ksplit > 1 && !a.partial) {

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -143,6 +144,11 @@ struct flowse_model {
     int act_dt = DT_F32;
     uint16_t* d_w16 = nullptr;
     int64_t d_w16_numel = 0;
+    // 3x3 convs with Cin % 32 == 0 and Cout % 128 == 0 again in MFMA fragment order (launch_pc16_weights) at the SAME offsets
+    // as in d_w16: the B operand of conv3x3_pc16_kernel's consumer waves, straight from L2
+    uint16_t* d_wfrag = nullptr;
+    int64_t d_wfrag_numel = 0;
+    std::set<int64_t> frag_offs;           // packed weight offsets that have fragment-order weights
     float* d_wino = nullptr;               // F(4,3) Winograd weights of the 3x3 convs the Winograd kernel can take
     int64_t d_wino_numel = 0;
     std::map<int64_t, int64_t> wino_of;    // packed weight offset (d_w) -> offset in d_wino

@@ -189,6 +189,7 @@ static void free_device_state(flowse_model* m) {
     if (m->d_ts) (void)hipFree(m->d_ts);
     if (m->d_wq) (void)hipFree(m->d_wq);
     if (m->d_w16) (void)hipFree(m->d_w16);
+    if (m->d_wfrag) (void)hipFree(m->d_wfrag);
     if (m->d_wino) (void)hipFree(m->d_wino);
     if (m->d_call) (void)hipFree(m->d_call);
     if (m->d_rk) (void)hipFree(m->d_rk);
@@ -205,7 +206,8 @@ static void free_device_state(flowse_model* m) {
     m->d_w = nullptr; m->d_ws = nullptr; m->d_ts = nullptr; m->d_wino = nullptr; m->d_call = nullptr;
     m->d_wq = nullptr;
     m->d_w16 = nullptr;
-    m->d_w_numel = m->d_wq_numel = m->d_wino_numel = m->d_w16_numel = 0;
+    m->d_wfrag = nullptr;
+    m->d_w_numel = m->d_wq_numel = m->d_wino_numel = m->d_w16_numel = m->d_wfrag_numel = 0;
     m->d_ws_bytes = m->d_ts_floats = 0;
     m->device = -1;
     if (sw) (void)hipSetDevice(cur);
@@ -399,6 +401,22 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
         }
         const int crc = launch_convert(m->d_w, DT_F32, m->d_w16, m->act_dt, (int64_t)pk.host.size() & ~(int64_t)3, nullptr);
         if (crc != OK) return crc;
+        // fragment-order copies for the producer / consumer 3x3 kernel, same offsets as in d_w16
+        m->frag_offs.clear();
+        if (m->d_wfrag && m->d_wfrag_numel < n16) {
+            FLOWSE_HIP(hipFree(m->d_wfrag));
+            m->d_wfrag = nullptr;
+        }
+        if (!m->d_wfrag) {
+            FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_wfrag), n16 * sizeof(uint16_t)));
+            m->d_wfrag_numel = n16;
+        }
+        for (auto& r : pk.wino) {
+            if ((r.Cout % 128) != 0 || (int64_t)r.Cout * 9 * r.Cin * 2 >= (1LL << 31)) continue;
+            const int frc = launch_pc16_weights(m->d_w16 + r.off, r.Cout, r.Cin, m->d_wfrag + r.off, nullptr);
+            if (frc != OK) return frc;
+            m->frag_offs.insert(r.off);
+        }
         pk.wino.clear();                     // no fp32 Winograd kernels run on 16-bit activations
     }
     // F(4,3) Winograd weights, derived on the device from the packed fp32 weights just uploaded
@@ -855,9 +873,9 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
     const bool halo = conv16_uses_halo(B, H, W, C1, C2, Cout, taps);
     const int ks = halo ? 1 : conv16_ksplit(B, H, W, (int)C, Cout, taps);
     const int64_t nw = ((int64_t)Cout * taps * C + 3) & ~(int64_t)3;
-    int64_t need = 2 * (M * C1 + M * C2 + nw + 2 * M * Cout) + 64 + (ks > 1 ? 4 * (int64_t)ks * M * Cout : 0);
-    if (scratch_bytes < need + 256) {
-        set_error("flowse_op_conv2d_16: scratch needs %lld bytes", (long long)(need + 256));
+    int64_t need = 2 * (M * C1 + M * C2 + 2 * nw + 2 * M * Cout) + 64 + (ks > 1 ? 4 * (int64_t)ks * M * Cout : 0);
+    if (scratch_bytes < need + 512) {
+        set_error("flowse_op_conv2d_16: scratch needs %lld bytes", (long long)(need + 512));
         return ERR_ARG;
     }
     if (gn_mean && !halo) {
@@ -869,6 +887,8 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
     void* a1 = take(2 * M * C1);
     void* a2 = C2 ? take(2 * M * C2) : nullptr;
     void* wq = take(2 * nw);
+    const bool frag = taps == 9 && conv16_uses_pc(B, H, W, C1, C2, Cout, taps);
+    void* wfrag = frag ? take(2 * nw) : nullptr;
     void* r16 = res ? take(2 * M * Cout) : nullptr;
     void* o16 = take(2 * M * Cout);
     float* part = ks > 1 ? reinterpret_cast<float*>(take(4 * (int64_t)ks * M * Cout)) : nullptr;
@@ -879,6 +899,7 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
     int rc = launch_convert(in1, DT_F32, a1, dt, M * C1, s);
     if (rc == OK && C2) rc = launch_convert(in2, DT_F32, a2, dt, M * C2, s);
     if (rc == OK) rc = launch_convert(w, DT_F32, wq, dt, nw, s);
+    if (rc == OK && frag) rc = launch_pc16_weights(wq, Cout, (int)C, wfrag, s);
     if (rc == OK && res) rc = launch_convert(res, DT_F32, r16, dt, M * Cout, s);
     if (rc != OK) return rc;
     ConvArgs c;
@@ -888,6 +909,7 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
     c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = taps; c.scale = scale;
     c.ksplit = ks; c.partial = part;
     c.wq = wq; c.terms = 1; c.wq_f16 = dt == DT_F16 ? 1 : 0;
+    c.wfrag = wfrag;
     c.in_dt = dt; c.out_dt = dt;
     if (gn_mean) {
         c.gn = GnParams{gn_mean, gn_scale, gn_beta};

@@ -266,6 +266,7 @@ struct Builder {
             c.out_dt = odt;
             if (in16) {                                   // [Cout][taps][Cin] in the storage type: same offsets as d_w
                 c.wq = M->d_w16 + w;
+                if (M->frag_offs.count(w)) c.wfrag = M->d_wfrag + w;
                 c.terms = 1;
                 c.wq_f16 = idt == DT_F16 ? 1 : 0;
             } else if (use_bf16) {
