@@ -16,6 +16,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-unused-function"] + os.environ.get("FLOWSE_BUILD_FLAGS", "").split()   # extra flags for A-B builds (tools/build_variants.py)
 
 
+# per-file extra flags.  conv16_pc.hip: its staging waves run beside an MFMA stream, where packed fp32 VALU instructions cost
+# more than the scalar ones they replace -- keep the SLP vectoriser from re-packing the scalar code (explicit vector types
+# in its output stage stay packed).
+EXTRA_FLAGS = {"conv16_pc.hip": ["-fno-slp-vectorize"]}
+
+
 def _digest():
     h = hashlib.sha256()
     files = [os.path.join(CSRC, n) for n in sorted(os.listdir(CSRC)) if not n.endswith(".o")]
@@ -26,6 +32,7 @@ def _digest():
             with open(path, "rb") as f:
                 h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -40,7 +47,7 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -44,6 +44,8 @@
 #define PC_TS_START
 #define PC_TS_ADD(K)
 #define PC_TS_FLUSH(BASE)
+#define PC_TS_ENTRY
+#define PC_TS_EXIT
 #endif
 
 namespace flowse {
@@ -211,6 +213,7 @@ template <int GN, bool F16>
 __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     using T16 = typename std::conditional<F16, f16_t, bf16_t>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    PC_TS_ENTRY
     char* Hs = reinterpret_cast<char*>(smem);              // [3][18][PC_HPITCH] at a pitch of PC_HBUF_X
     float* red = reinterpret_cast<float*>(Hs + 3 * PC_HBUF_X);
     float* tscr = red + PC_RED / 4;                        // [4 consumer waves][32][PCW_PITCH]
@@ -262,11 +265,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
             __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wfrag), 0, a.Cout * 9 * Cin * 2, 0x00020000);
         const unsigned bvo = (unsigned)lane * 16u;
         const unsigned jstride = (unsigned)nchunks * PCF_CHUNK;   // bytes between two 32-channel blocks
-        auto wsoff = [&](int g) {                          // byte offset of (32-channel block wn * 2, chunk) of stream chunk g
-            g = min(g, Ctot - 1);
-            const int k = g / nchunks;
-            const PcItem p = item_at(k);
-            return (unsigned)__builtin_amdgcn_readfirstlane((((p.n0 >> 5) + wn * 2) * nchunks + (g - k * nchunks)) * PCF_CHUNK);
+        // byte offset of (32-channel block wn * 2, chunk) in the fragment-order weights, advanced by one chunk per call
+        // (no division per chunk); beyond the stream's end the last chunk again
+        int wq_g = -1, wq_k = 0, wq_chunk = -1;
+        int wq_nb = (item_at(0).n0 >> 5) + wn * 2;
+        auto wsoff_next = [&]() {
+            if (!(wq_g + 1 >= Ctot && wq_g >= 0)) {
+                ++wq_g;
+                if (++wq_chunk == nchunks) {
+                    wq_chunk = 0;
+                    ++wq_k;
+                    wq_nb = (item_at(wq_k).n0 >> 5) + wn * 2;
+                }
+            }
+            return (unsigned)__builtin_amdgcn_readfirstlane((wq_nb * nchunks + wq_chunk) * PCF_CHUNK);
         };
         f32x16 acc[2][2][2];
         auto zero_acc = [&]() {
@@ -297,34 +309,54 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) _Pragma("unroll") for (int j = 0; j < 2; ++j)                   \
         wb[RING][mh][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                          \
             rsrcw, bvo, (SOFF) + (unsigned)j * jstride + (unsigned)((TAPV) * PCF_STEP + mh * 1024), 0));
-#define FLOWSE_PC_MMA(FA, FB)                                                                                        \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i)                      \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
-        if (F16)                                                                                                     \
-            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, FA[t][i]),               \
-                                                                 __builtin_bit_cast(f16x8, FB[j]), acc[t][i][j], 0, 0, 0); \
-        else                                                                                                         \
-            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[t][i], FB[j], acc[t][i][j], 0, 0, 0);          \
-    }
-        // One step at tap TAP of the current chunk (halo buffer offset hoff, B ring entry TAP % 3).  Entering, set X holds the
-        // A fragments of (TAP, mh 0); leaving, those of the next step's mh 0 (across a chunk boundary too: the next chunk's halo
-        // is complete since the barrier of THIS chunk).  The ring entry is refilled with step + 3.  In a tile's last chunk
-        // nothing of the next tile is requested (its ring comes from inside the output stage, its first A fragments after
-        // it); the ring registers freed at taps 6 and 7 take the residuals of the output stage's first two rounds.
+        // One step at tap TAP of the current chunk (halo buffer offset hoff, B ring entry R = TAP % 3): 16 MFMAs with every other
+        // instruction of the step placed in the gap behind ONE of them -- a lone MFMA wave hides at most ~5 issue slots per
+        // 32-cycle MFMA (MI355X_MICROARCH.md), and in clumps (four ds_read + four buffer_load + their scalar adds behind one
+        // MFMA, as the compiler's own order had it) the loop ran at 41 cycles per MFMA (tools/pc16_ts.py).  Gap after MFMA
+        //   1-4   this tap's second-half A fragments (set Y),        7, 8   refill of ring entry R, first half (step + 3),
+        //   9-12  the next step's first-half A fragments (set X),    15, 16 refill of ring entry R, second half.
+        // Branch-free: across a chunk boundary the next halo is complete since the barrier of THIS chunk; in a tile's last
+        // chunk the requests for "the next chunk" are redundant (the ring is re-requested after the output stage, entries 0-2
+        // meanwhile take the residuals: FLOWSE_PC_RESLOAD).
+#define FLOWSE_PC_A1(FA, T_, I_, HOFF, TAP, MH)                                                                      \
+    FA[T_][I_] = *reinterpret_cast<const bf16x8*>(Hs + (HOFF) + (((TAP) / 3 - 1) * PC_HPITCH + ((TAP) % 3 - 1) * PC_ROWB + \
+                                                                (MH) * 32 + (T_) * 8 * PC_HPITCH) + abase[I_]);      \
+    __builtin_amdgcn_sched_barrier(0);
+#define FLOWSE_PC_W1(R, MH, J_, SOFF, TAPV)                                                                          \
+    wb[R][MH][J_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                                \
+        rsrcw, bvo + (unsigned)(((TAPV) & 1) * PCF_STEP + (MH) * 1024),                                              \
+        (SOFF) + (unsigned)(J_) * jstride + (unsigned)(((TAPV) >> 1) * 2 * PCF_STEP), 0));                           \
+    __builtin_amdgcn_sched_barrier(0);
+#define FLOWSE_PC_M1(FA, T_, I_, J_, R, MH)                                                                          \
+    if (F16)                                                                                                         \
+        acc[T_][I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, FA[T_][I_]),              \
+                                                                __builtin_bit_cast(f16x8, wb[R][MH][J_]), acc[T_][I_][J_], 0, 0, 0); \
+    else                                                                                                             \
+        acc[T_][I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[T_][I_], wb[R][MH][J_], acc[T_][I_][J_], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+#define FLOWSE_PC_REFILL(R, MH, J_, TAP)                                                                             \
+    if constexpr ((TAP) + 3 < 9) { FLOWSE_PC_W1(R, MH, J_, wcur, (TAP) + 3) } else { FLOWSE_PC_W1(R, MH, J_, wnext, (TAP) + 3 - 9) }
+#define FLOWSE_PC_NEXTA(T_, I_, TAP)                                                                                 \
+    if constexpr ((TAP) < 8) { FLOWSE_PC_A1(xa, T_, I_, hoff, (TAP) + 1, 0) } else { FLOWSE_PC_A1(xa, T_, I_, hnext, 0, 0) }
 #define FLOWSE_PC_STEP(TAP)                                                                                          \
     {                                                                                                                \
-        FLOWSE_PC_LOADA(ya, hoff, (TAP), 1)                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        FLOWSE_PC_MMA(xa, wb[(TAP) % 3][0])                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if constexpr ((TAP) < 8) { FLOWSE_PC_LOADA(xa, hoff, ((TAP) + 1) % 9, 0) }                                   \
-        else if (!tile_end) { FLOWSE_PC_LOADA(xa, hnext, 0, 0) }                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        FLOWSE_PC_MMA(ya, wb[(TAP) % 3][1])                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if constexpr ((TAP) + 3 < 9) { FLOWSE_PC_WLOAD((TAP) % 3, wcur, (TAP) + 3) }                                 \
-        else if (!tile_end) { FLOWSE_PC_WLOAD((TAP) % 3, wnext, (TAP) + 3 - 9) }                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        constexpr int R = (TAP) % 3;                                                                                 \
+        FLOWSE_PC_M1(xa, 0, 0, 0, R, 0) FLOWSE_PC_A1(ya, 0, 0, hoff, (TAP), 1)                                       \
+        FLOWSE_PC_M1(xa, 0, 0, 1, R, 0) FLOWSE_PC_A1(ya, 0, 1, hoff, (TAP), 1)                                       \
+        FLOWSE_PC_M1(xa, 0, 1, 0, R, 0) FLOWSE_PC_A1(ya, 1, 0, hoff, (TAP), 1)                                       \
+        FLOWSE_PC_M1(xa, 0, 1, 1, R, 0) FLOWSE_PC_A1(ya, 1, 1, hoff, (TAP), 1)                                       \
+        FLOWSE_PC_M1(xa, 1, 0, 0, R, 0)                                                                              \
+        FLOWSE_PC_M1(xa, 1, 0, 1, R, 0)                                                                              \
+        FLOWSE_PC_M1(xa, 1, 1, 0, R, 0) FLOWSE_PC_REFILL(R, 0, 0, TAP)                                               \
+        FLOWSE_PC_M1(xa, 1, 1, 1, R, 0) FLOWSE_PC_REFILL(R, 0, 1, TAP)                                               \
+        FLOWSE_PC_M1(ya, 0, 0, 0, R, 1) FLOWSE_PC_NEXTA(0, 0, TAP)                                                   \
+        FLOWSE_PC_M1(ya, 0, 0, 1, R, 1) FLOWSE_PC_NEXTA(0, 1, TAP)                                                   \
+        FLOWSE_PC_M1(ya, 0, 1, 0, R, 1) FLOWSE_PC_NEXTA(1, 0, TAP)                                                   \
+        FLOWSE_PC_M1(ya, 0, 1, 1, R, 1) FLOWSE_PC_NEXTA(1, 1, TAP)                                                   \
+        FLOWSE_PC_M1(ya, 1, 0, 0, R, 1)                                                                              \
+        FLOWSE_PC_M1(ya, 1, 0, 1, R, 1)                                                                              \
+        FLOWSE_PC_M1(ya, 1, 1, 0, R, 1) FLOWSE_PC_REFILL(R, 1, 0, TAP)                                               \
+        FLOWSE_PC_M1(ya, 1, 1, 1, R, 1) FLOWSE_PC_REFILL(R, 1, 1, TAP)                                               \
     }
 #define FLOWSE_PC_RESLOAD(R)                               /* residual of output round R into ring entry R (see pc16_out_wide) */ \
     if (tile_end && has_res) {                                                                                       \
@@ -352,7 +384,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         };
         set_out();
         int hoff = 0;                                      // byte offset of the current chunk's halo buffer
-        unsigned wcur = wsoff(0), wnext = wsoff(1);
+        unsigned wcur = wsoff_next();
+        unsigned wnext = wsoff_next();
         FLOWSE_PC_WLOAD(0, wcur, 0) FLOWSE_PC_WLOAD(1, wcur, 1) FLOWSE_PC_WLOAD(2, wcur, 2)
         __syncthreads();                                   // (X 0)
         FLOWSE_PC_LOADA(xa, 0, 0, 0)
@@ -380,12 +413,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
             }
             hoff = hnext;
             wcur = wnext;
-            wnext = wsoff(gc + 2);
+            wnext = wsoff_next();
         }
+        PC_TS_EXIT
         if (wave == 0) { PC_TS_FLUSH(0) }                  // slots 0-7 of the block
 #undef FLOWSE_PC_RESLOAD
 #undef FLOWSE_PC_STEP
-#undef FLOWSE_PC_MMA
+#undef FLOWSE_PC_NEXTA
+#undef FLOWSE_PC_REFILL
+#undef FLOWSE_PC_M1
+#undef FLOWSE_PC_W1
+#undef FLOWSE_PC_A1
 #undef FLOWSE_PC_WLOAD
 #undef FLOWSE_PC_LOADA
         return;
@@ -395,132 +433,149 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     const int ltid = tid - 256;
     const int octet = ltid & 3;                            // this thread's 8-channel group inside a 32-channel chunk
     const int hp0 = ltid >> 2;                             // halo pixels hp0 + 64 q
-    // Window coordinates of the thread's pieces, packed (hy | hx << 8) two per register, made opaque where used so that
-    // nothing derived from them is hoisted into long-lived registers.
-    unsigned hyx[PC_PIECES / 2];
-#pragma unroll
-    for (int q = 0; q < PC_PIECES; ++q) {
-        const int hp = hp0 + 64 * q;
-        const int hy = hp / 18, hx = hp - hy * 18;
-        const unsigned pk = (unsigned)hy | ((unsigned)hx << 8);
-        if (q & 1) hyx[q >> 1] |= pk << 16; else hyx[q >> 1] = pk;
-    }
-    const bool last_valid = hp0 + 64 * (PC_PIECES - 1) < 324;      // piece 5 exists for 16 threads only
-    int hlds[PC_PIECES];                                   // LDS byte offset of each piece inside a halo buffer
+    // Per piece, fixed for the whole launch: its LDS byte offset inside a halo buffer and its byte offset inside the 18 x 18
+    // window of either source tensor.  Per (tile, chunk) only a descriptor, a scalar offset and six selects remain: the
+    // per-chunk window arithmetic and bounds tests (~100 VALU instructions) cost the staging waves as much as half a
+    // normalisation burst (tools/pc16_ts.py: "requests").
+    int hlds[PC_PIECES];
+    unsigned offA[PC_PIECES], offB[PC_PIECES];
+    unsigned hyx[PC_PIECES / 2];                           // window coordinates (hy | hx << 8), two per register: the per-tile bounds mask
 #pragma unroll
     for (int q = 0; q < PC_PIECES; ++q) {
         const int hp = hp0 + 64 * q;
         const int hy = hp / 18, hx = hp - hy * 18;
         hlds[q] = hy * PC_HPITCH + hx * PC_ROWB + octet * 16;
+        offA[q] = (unsigned)(((hy * W + hx) * C1 + octet * 8) * 2);
+        offB[q] = (unsigned)(((hy * W + hx) * C2 + octet * 8) * 2);
+        const unsigned pk = (unsigned)hy | ((unsigned)hx << 8);
+        if (q & 1) hyx[q >> 1] |= pk << 16; else hyx[q >> 1] = pk;
     }
-    auto h_y = [&](int q) { return (hyx[q >> 1] >> ((q & 1) * 16)) & 0xffu; };
-    auto h_x = [&](int q) { return (hyx[q >> 1] >> ((q & 1) * 16 + 8)) & 0xffu; };
+    const bool last_valid = hp0 + 64 * (PC_PIECES - 1) < 324;      // piece 5 exists for 16 threads only
     const T16* in1p = reinterpret_cast<const T16*>(a.in1);
     const T16* in2p = reinterpret_cast<const T16*>(a.in2);
     const int wpix = 17 * W + 18;
 
-    // stream cursor: (item, chunk) of global chunk index g, clamped to the stream's last chunk (a redundant reload at the
-    // very end keeps every load unconditional)
-    struct Cur {
-        PcItem p;
-        int chunk;
+    // stream position of the requests, advanced by one chunk per HLOAD (no division per request: every instruction of these
+    // waves competes with the MFMA stream for issue, ~10 cycles apiece): chunk rq_chunk of item rq_k, the item's coordinates
+    // and the in-image mask of this thread's pieces.  Beyond the stream's end the last chunk is requested again.
+    int rq_g = -1, rq_k = 0, rq_chunk = -1;
+    PcItem rq_p = item_at(0);
+    unsigned rq_mask = 0;
+    auto rq_item = [&]() {
+        unsigned m = 0;
+#pragma unroll
+        for (int q = 0; q < PC_PIECES; ++q) {
+            const unsigned hy = (hyx[q >> 1] >> ((q & 1) * 16)) & 0xffu, hx = (hyx[q >> 1] >> ((q & 1) * 16 + 8)) & 0xffu;
+            const bool in = (q < PC_PIECES - 1 || last_valid) && (unsigned)(rq_p.y0 - 1 + (int)hy) < (unsigned)H &&
+                            (unsigned)(rq_p.x0 - 1 + (int)hx) < (unsigned)W;
+            m |= in ? (1u << q) : 0u;
+        }
+        rq_mask = m;
     };
-    auto cursor = [&](int g) {
-        g = min(g, Ctot - 1);
-        const int k = g / nchunks;
-        Cur c;
-        c.p = item_at(k);
-        c.chunk = g - k * nchunks;
-        return c;
+    rq_item();
+    auto rq_next = [&]() {
+        if (rq_g + 1 >= Ctot && rq_g >= 0) return;         // (uniform) clamp: stay on the last chunk
+        ++rq_g;
+        if (++rq_chunk == nchunks) {
+            rq_chunk = 0;
+            ++rq_k;
+            rq_p = item_at(rq_k);
+            rq_item();
+        }
     };
-    // raw halo pieces of chunk `c` (8 consecutive channels of a pixel per piece; out-of-image pixels read 0)
+    // raw halo pieces (8 consecutive channels of a pixel per piece; out-of-image pixels read 0)
     u32x4 ra[PC_PIECES], rb[PC_PIECES];                    // two chunks in flight
     unsigned hin_a = 0, hin_b = 0;                         // in-image bits of the pieces held in ra / rb
-    f32x2 sca[4], sha[4], scb[4], shb[4];                  // folded GroupNorm affine y = x sc + sh per channel pair, two chunks' worth
-#define FLOWSE_PC_HLOAD(R, HIN, CURV)                                                                                \
+    // GroupNorm parameters of the thread's 8 channels, two chunks' worth
+    struct PcAff {
+        float4 m[2], s[2], b[2];
+    };
+    PcAff pa, pb;
+    // requests of the next stream chunk: raw pieces into R, their in-image bits into HIN, the GroupNorm parameters into Q
+#define FLOWSE_PC_HLOAD(R, HIN, Q)                                                                                   \
     {                                                                                                                \
-        const Cur& cc = (CURV);                                                                                      \
-        const int c0 = cc.chunk * KC;                                                                                \
+        rq_next();                                                                                                   \
+        const int chunk = rq_chunk;                                                                                  \
+        const int c0 = chunk * KC;                                                                                   \
         const bool second = c0 >= C1;                                                                                \
         const unsigned cs = (unsigned)(second ? C2 : C1);                                                            \
-        const int64_t wbase = ((int64_t)cc.p.b * H + cc.p.y0 - 1) * W + cc.p.x0 - 1;                                 \
+        const int64_t wbase = ((int64_t)rq_p.b * H + rq_p.y0 - 1) * W + rq_p.x0 - 1;                                 \
         const uint64_t wsel = reinterpret_cast<uint64_t>((second ? in2p : in1p) + wbase * (int64_t)cs);              \
         const uint64_t wuni = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wsel) |              \
                               ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wsel >> 32)) << 32); \
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(                                       \
             reinterpret_cast<T16*>(wuni), 0, __builtin_amdgcn_readfirstlane(wpix * (int)cs * 2), 0x00020000);        \
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((second ? c0 - C1 : c0) * 2);                 \
-        unsigned hin = 0;                                                                                            \
-        _Pragma("unroll") for (int k = 0; k < PC_PIECES / 2; ++k) asm volatile("" : "+v"(hyx[k]));                   \
         _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
-            const unsigned hy = h_y(q), hx = h_x(q);                                                                 \
-            const bool in = (q < PC_PIECES - 1 || last_valid) && (unsigned)(cc.p.y0 - 1 + (int)hy) < (unsigned)H &&  \
-                            (unsigned)(cc.p.x0 - 1 + (int)hx) < (unsigned)W;                                         \
-            hin |= in ? (1u << q) : 0u;                                                                              \
-            const unsigned off = in ? ((hy * (unsigned)W + hx) * cs + (unsigned)octet * 8u) * 2u : OOB;              \
+            const unsigned off = ((rq_mask >> q) & 1u) ? (second ? offB[q] : offA[q]) : OOB;                         \
             R[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, soff, 0);                                        \
         }                                                                                                            \
-        HIN = hin;                                                                                                   \
+        HIN = rq_mask;                                                                                               \
+        load_params(rq_p.b, chunk, Q);                                                                               \
     }
-    // GroupNorm parameters of the chunk at `cc`, folded: y = (x - mean) scale + beta = x scale + (beta - mean scale)
-    auto load_params = [&](const Cur& cc, f32x2 (&scv)[4], f32x2 (&shv)[4]) {
+    // GroupNorm parameters of (sample b, chunk): REQUESTED here (raw mean / scale / beta of the thread's 8 channels), folded by
+    // the burst that uses them a chunk later -- folded on arrival, every request waited ~1 900 cycles for these loads
+    auto load_params = [&](int b, int chunk, PcAff& q) {
         if (!GN) return;
-        const int cg = cc.chunk * KC + octet * 8;
-        const float* mp = a.gn.mean + (int64_t)cc.p.b * Cin + cg;
-        const float* sp = a.gn.scale + (int64_t)cc.p.b * Cin + cg;
+        const int cg = chunk * KC + octet * 8;
+        const float* mp = a.gn.mean + (int64_t)b * Cin + cg;
+        const float* sp = a.gn.scale + (int64_t)b * Cin + cg;
         const float* bp = a.gn.beta + cg;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float4 m4 = *reinterpret_cast<const float4*>(mp + 4 * h);
-            const float4 s4 = *reinterpret_cast<const float4*>(sp + 4 * h);
-            const float4 b4 = *reinterpret_cast<const float4*>(bp + 4 * h);
-            scv[2 * h] = f32x2{s4.x, s4.y};
-            scv[2 * h + 1] = f32x2{s4.z, s4.w};
-            shv[2 * h] = f32x2{fmaf(-m4.x, s4.x, b4.x), fmaf(-m4.y, s4.y, b4.y)};
-            shv[2 * h + 1] = f32x2{fmaf(-m4.z, s4.z, b4.z), fmaf(-m4.w, s4.w, b4.w)};
+            q.m[h] = *reinterpret_cast<const float4*>(mp + 4 * h);
+            q.s[h] = *reinterpret_cast<const float4*>(sp + 4 * h);
+            q.b[h] = *reinterpret_cast<const float4*>(bp + 4 * h);
         }
     };
-    // The raw pieces RX (parameters (SCX, SHX)) of one chunk are normalised into the halo buffer at byte offset HB, stage by
-    // stage over ALL pieces (24 channel pairs): a lone wave hides no latency by itself -- piece after piece the dependent
-    // unpack -> fma -> exp -> rcp -> mul chains ran at ~10 cycles per instruction, 24 independent pairs per stage keep the
-    // VALU issuing (2 900 vs 3 300 cycles per chunk, tools/pc16_ts.py).
-#define FLOWSE_PC_BURST(RX, HINX, SCX, SHX, HB)                                                                      \
+    // The raw pieces RX (parameters Q) of one chunk are normalised into the halo buffer at byte offset HB, stage by stage over
+    // ALL pieces (48 values): a lone wave hides no latency by itself -- piece after piece the dependent unpack -> fma -> exp ->
+    // rcp -> mul chains ran at ~10 cycles per instruction, 48 independent values per stage keep the VALU issuing.  SCALAR
+    // fp32 instructions on purpose (this translation unit is built with -fno-slp-vectorize): the staging now runs beside the
+    // consumers' MFMA stream, where a packed fp32 instruction costs ~20 cycles more than the two scalar ones it replaces
+    // (MI355X_MICROARCH.md; here: 26 k vs ... cycles of staging per tile, tools/pc16_ts.py).
+#define FLOWSE_PC_BURST(RX, HINX, Q, HB)                                                                             \
     if (GN) {                                                                                                        \
-        f32x2 v[PC_PIECES][4], z[PC_PIECES][4];                                                                      \
-        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
-            const unsigned wsrc[4] = {RX[q].x, RX[q].y, RX[q].z, RX[q].w};                                           \
+        /* folded affine: y = (x - mean) scale + beta = x sc + sh; SiLU exponent -log2(e) y = x ec + eh */           \
+        float sc[8], sh[8], ec[8], eh[8];                                                                            \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                              \
+            const float mm[4] = {Q.m[h].x, Q.m[h].y, Q.m[h].z, Q.m[h].w}, ss[4] = {Q.s[h].x, Q.s[h].y, Q.s[h].z, Q.s[h].w}; \
+            const float bb[4] = {Q.b[h].x, Q.b[h].y, Q.b[h].z, Q.b[h].w};                                            \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
-                float u0, u1;                                                                                        \
-                St<T16>::unpack2(wsrc[e], u0, u1);                                                                   \
-                v[q][e] = f32x2{u0, u1};                                                                             \
+                sc[4 * h + e] = ss[e];                                                                               \
+                sh[4 * h + e] = __builtin_fmaf(-mm[e], ss[e], bb[e]);                                                \
+                ec[4 * h + e] = -1.44269504088896341f * sc[4 * h + e];                                               \
+                eh[4 * h + e] = -1.44269504088896341f * sh[4 * h + e];                                               \
             }                                                                                                        \
         }                                                                                                            \
-        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e)          \
-            v[q][e] = __builtin_elementwise_fma(v[q][e], SCX[e], SHX[e]);                                            \
+        float v[PC_PIECES][8], z[PC_PIECES][8];                                                                      \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
+            const unsigned wsrc[4] = {RX[q].x, RX[q].y, RX[q].z, RX[q].w};                                           \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) St<T16>::unpack2(wsrc[e], v[q][2 * e], v[q][2 * e + 1]);   \
+        }                                                                                                            \
         if (GN == 2) {                                                                                               \
-            const f32x2 nl2e = {-1.44269504088896341f, -1.44269504088896341f}, one = {1.f, 1.f};                     \
-            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e)      \
-                z[q][e] = v[q][e] * nl2e;                                                                            \
-            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e) {    \
-                z[q][e].x = __builtin_amdgcn_exp2f(z[q][e].x);                                                       \
-                z[q][e].y = __builtin_amdgcn_exp2f(z[q][e].y);                                                       \
-            }                                                                                                        \
-            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e)      \
-                z[q][e] += one;                                                                                      \
-            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e) {    \
-                z[q][e].x = __builtin_amdgcn_rcpf(z[q][e].x);                                                        \
-                z[q][e].y = __builtin_amdgcn_rcpf(z[q][e].y);                                                        \
-            }                                                                                                        \
-            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e)      \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
+                z[q][e] = __builtin_fmaf(v[q][e], ec[e], eh[e]);                                                     \
+        }                                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)          \
+            v[q][e] = __builtin_fmaf(v[q][e], sc[e], sh[e]);                                                         \
+        if (GN == 2) {                                                                                               \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
+                z[q][e] = __builtin_amdgcn_exp2f(z[q][e]);                                                           \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
+                z[q][e] += 1.f;                                                                                      \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
+                z[q][e] = __builtin_amdgcn_rcpf(z[q][e]);                                                            \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
                 v[q][e] *= z[q][e];                                                                                  \
         }                                                                                                            \
         _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
             const unsigned keepm = (((HINX) >> q) & 1u) ? 0xffffffffu : 0u;   /* zero padding AFTER the activation */ \
             u32x4 t;                                                                                                 \
-            t.x = pc_pack2<F16>(v[q][0].x, v[q][0].y) & keepm;                                                       \
-            t.y = pc_pack2<F16>(v[q][1].x, v[q][1].y) & keepm;                                                       \
-            t.z = pc_pack2<F16>(v[q][2].x, v[q][2].y) & keepm;                                                       \
-            t.w = pc_pack2<F16>(v[q][3].x, v[q][3].y) & keepm;                                                       \
+            t.x = pc_pack2<F16>(v[q][0], v[q][1]) & keepm;                                                           \
+            t.y = pc_pack2<F16>(v[q][2], v[q][3]) & keepm;                                                           \
+            t.z = pc_pack2<F16>(v[q][4], v[q][5]) & keepm;                                                           \
+            t.w = pc_pack2<F16>(v[q][6], v[q][7]) & keepm;                                                           \
             if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) + hlds[q]) = t;                 \
         }                                                                                                            \
     } else {                                                                                                         \
@@ -529,19 +584,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     }
 
     // ---- prologue: chunks 0 and 1 -> buffers 0 and 1; raw pieces of chunks 2 and 3 in flight
-    {
-        const Cur c0 = cursor(0), c1 = cursor(1), c2 = cursor(2), c3 = cursor(3);
-        FLOWSE_PC_HLOAD(ra, hin_a, c0)
-        load_params(c0, sca, sha);
-        FLOWSE_PC_HLOAD(rb, hin_b, c1)
-        load_params(c1, scb, shb);
-        FLOWSE_PC_BURST(ra, hin_a, sca, sha, 0)
-        FLOWSE_PC_HLOAD(ra, hin_a, c2)
-        load_params(c2, sca, sha);
-        FLOWSE_PC_BURST(rb, hin_b, scb, shb, PC_HBUF_X)
-        FLOWSE_PC_HLOAD(rb, hin_b, c3)
-        load_params(c3, scb, shb);
-    }
+    FLOWSE_PC_HLOAD(ra, hin_a, pa)
+    FLOWSE_PC_HLOAD(rb, hin_b, pb)
+    FLOWSE_PC_BURST(ra, hin_a, pa, 0)
+    FLOWSE_PC_HLOAD(ra, hin_a, pa)
+    FLOWSE_PC_BURST(rb, hin_b, pb, PC_HBUF_X)
+    FLOWSE_PC_HLOAD(rb, hin_b, pb)
     PC_TS_DECL
     PC_TS_START
     int cit = 0;
@@ -551,19 +599,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     // of chunk gc + GO + 4 are requested into the same registers.  The staging runs a whole chunk ahead of what the next
     // barrier needs, so the consumers never wait for it unless the producers fall a chunk behind (output stage: the bursts
     // of the next tile's first two chunks are done before the tile's barrier (S)).
-#define FLOWSE_PC_LCHUNK(GO, RX, HINX, SCX, SHX)                                                                     \
+#define FLOWSE_PC_LCHUNK(GO, RX, HINX, Q)                                                                            \
     {                                                                                                                \
         const bool tile_end = cit == nchunks - 1;                                                                    \
         __syncthreads();                                   /* (X gc + GO) */                                        \
         PC_TS_ADD(1)                                       /* 1: chunk barrier */                                   \
-        if (gc + (GO) + 2 < Ctot) { FLOWSE_PC_BURST(RX, HINX, SCX, SHX, hb) }                                        \
+        if (gc + (GO) + 2 < Ctot) { FLOWSE_PC_BURST(RX, HINX, Q, hb) }                                               \
         hb = hb == 2 * PC_HBUF_X ? 0 : hb + PC_HBUF_X;                                                               \
         PC_TS_ADD(4)                                       /* 4: halo burst */                                      \
-        {                                                                                                            \
-            const Cur c4 = cursor(gc + (GO) + 4);                                                                    \
-            FLOWSE_PC_HLOAD(RX, HINX, c4)                                                                            \
-            load_params(c4, SCX, SHX);                                                                               \
-        }                                                                                                            \
+        FLOWSE_PC_HLOAD(RX, HINX, Q)                        /* chunk gc + GO + 4 */                                  \
         PC_TS_ADD(0)                                       /* 0: requests */                                        \
         ++cit;                                                                                                       \
         if (tile_end) {                                                                                              \
@@ -573,11 +617,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         }                                                                                                            \
     }
     for (int gc = 0; gc < Ctot; gc += 2) {
-        FLOWSE_PC_LCHUNK(0, ra, hin_a, sca, sha)           // ra holds chunk gc + 2
-        if (gc + 1 < Ctot) { FLOWSE_PC_LCHUNK(1, rb, hin_b, scb, shb) }       // rb holds chunk gc + 3
+        FLOWSE_PC_LCHUNK(0, ra, hin_a, pa)                 // ra holds chunk gc + 2
+        if (gc + 1 < Ctot) { FLOWSE_PC_LCHUNK(1, rb, hin_b, pb) }             // rb holds chunk gc + 3
     }
 #undef FLOWSE_PC_LCHUNK
 #undef FLOWSE_PC_BURST
+    PC_TS_EXIT
     if (wave == 4) { PC_TS_FLUSH(8) }                      // slots 8-15 of the block
 #undef FLOWSE_PC_HLOAD
 }

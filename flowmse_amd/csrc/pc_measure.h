@@ -11,6 +11,12 @@ extern "C" int flowse_debug_pc_ts(unsigned long long* host, int n) {
 }
 #define PC_TS_DECL unsigned long long pc_t0 = 0, pc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PC_TS_START pc_t0 = __builtin_amdgcn_s_memtime();
+// whole-kernel brackets: shader-clock ticks (slot 5) and the constant 100 MHz counter (slot 6) from kernel entry to the end of
+// the role's loop -- calibrates ticks against wall time and shows what the per-phase accumulators do not cover
+#define PC_TS_ENTRY const unsigned long long pc_e0 = __builtin_amdgcn_s_memtime(), pc_r0 = __builtin_amdgcn_s_memrealtime();
+#define PC_TS_EXIT                                                  \
+    pc_acc[5] = __builtin_amdgcn_s_memtime() - pc_e0;               \
+    pc_acc[6] = __builtin_amdgcn_s_memrealtime() - pc_r0;
 // add the time since the last mark to accumulator K
 #define PC_TS_ADD(K)                                               \
     {                                                              \

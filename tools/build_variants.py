@@ -34,7 +34,7 @@ def build_variant(name, flags):
     for src in fb.SOURCES:
         obj = os.path.join(out, src.replace(".hip", ".o"))
         objs.append(obj)
-        procs.append((src, subprocess.Popen([hipcc] + base + flags.split() + ["-c", os.path.join(fb.CSRC, src), "-o", obj],
+        procs.append((src, subprocess.Popen([hipcc] + base + fb.EXTRA_FLAGS.get(src, []) + flags.split() + ["-c", os.path.join(fb.CSRC, src), "-o", obj],
                                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         o, _ = p.communicate()

@@ -58,8 +58,10 @@ def main():
     buf = (C.c_ulonglong * (256 * 16))()
     raw.flowse_debug_pc_ts(buf, 256 * 16)
     t = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16).astype(np.float64)
-    names = ["cons: frag+mfma", "cons: chunk barrier", "", "cons: output stage", "", "", "", "",
-             "prod: requests", "prod: chunk barrier", "", "prod: output-stage wait", "prod: halo bursts"]
+    names = ["cons: frag+mfma", "cons: chunk barrier", "", "cons: output stage", "", "cons: kernel entry -> loop end (ticks)",
+             "cons: the same on the 100 MHz counter", "",
+             "prod: requests", "prod: chunk barrier", "", "prod: output-stage wait", "prod: halo bursts",
+             "prod: kernel entry -> loop end (ticks)", "prod: the same on the 100 MHz counter"]
     for k, n in enumerate(names):
         if n:
             print(f"  {n:22s} median {np.median(t[:, k]):10.0f}  min {t[:, k].min():10.0f}  max {t[:, k].max():10.0f} cycles")
