@@ -83,8 +83,11 @@ template <> struct St<f16_t> {
     static constexpr int dt = DT_F16;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ unsigned pack2(float a, float b) {
-        const _Float16 x = (_Float16)a, y = (_Float16)b;
-        return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+        // round to nearest even in ONE instruction (gfx950); bit-identical to two (_Float16) casts over all 2^32 fp32
+        // patterns in both slots (tools/probes/cvt_pk_f16.hip)
+        unsigned r;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
     }
     static __device__ __forceinline__ void unpack2(unsigned w, float& a, float& b) {
         a = (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));

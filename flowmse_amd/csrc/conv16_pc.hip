@@ -5,37 +5,36 @@
 //
 // Structure (ONE persistent block per CU, eight waves, tiles of 16 x 16 pixels x 128 output channels dealt to the blocks in
 // XCD-contiguous ranges):
-//   * Waves 0-3 ("consumers", one per SIMD) only read MFMA fragments from LDS and issue MFMAs: 16 per (tap, 32-channel
-//     chunk) step and wave in two halves of 16 channels, the fragments of the next half requested before the MFMAs of the
-//     current one.  They never wait for memory and carry no VALU work in the main loop.
-//   * Waves 4-7 ("producers", one per SIMD) run ahead on the SAME stream of steps: raw halo pieces (16 bytes = 8 channels of
-//     a pixel) are requested a whole chunk before they are needed, weight tiles eleven steps ahead (a ring of nine register
-//     sets) and written to LDS two steps ahead.  Their global loads stay in flight across the block barrier (plain loads, no
-//     LDS-DMA: __syncthreads() then only waits for LDS traffic).
-//   * One barrier per step.  In interval s consumers READ weight slots s % 3 and (s + 1) % 3 and producers WRITE slot
-//     (s + 2) % 3.
-//   * GroupNorm + SiLU of a chunk's halo (affine folded to one FMA per element, v_exp / v_rcp, one rounding to the operand
-//     type) runs as ONE burst per chunk at a barrier pair (T) during which the consumers issue nothing; the burst for a
-//     tile's first chunk runs under the previous tile's output stage.
-//   * Output stage in the consumers (pc16_out_wide): 16-byte residual loads / stores through wave-private LDS transposition
-//     tiles, GroupNorm partial statistics of the tensor written; its block barrier (S) is the tile hand-over point.
-// LDS: 2 halo buffers [18][18 px x 80 B + 96] (32 KB apart) + 3 weight slots [128][80 B] + statistics scratch + the output
-// stage's four transposition tiles = 133 KB.
+//   * Waves 0-3 ("consumers", one per SIMD): A fragments from the LDS halo, B fragments STRAIGHT FROM L2 -- the weights are
+//     kept a second time in MFMA fragment order (pc16_weights_kernel: one 1 KB line per wave-level B operand) and travel
+//     through a ring of three register sets, requested three steps ahead -- and 16 MFMAs per (tap, 32-channel chunk) step.
+//     Every other instruction of a step sits in the gap behind ONE MFMA (FLOWSE_PC_STEP).  No weight tile in LDS, hence no
+//     barrier per step.
+//   * Waves 4-7 ("producers", one per SIMD) stage halos only: raw 16-byte pieces (8 channels of a pixel) requested four
+//     chunks ahead, GroupNorm + SiLU (affine folded to one FMA, v_exp / v_rcp, one rounding to the operand type) two chunks
+//     to three chunks ahead into one of FOUR halo buffers, in scalar fp32 instructions.
+//   * ONE barrier per chunk (X): the consumers are done with the previous chunk's buffer, the staged chunks are visible.
+//   * Output stage in the consumers (pc16_out_wide): wave-private LDS transposition tiles, 16-byte stores, residuals
+//     requested into the idle B ring during the tile's last three steps, GroupNorm partial statistics of the tensor
+//     written; its block barrier (S, for the statistics exchange between the two pixel halves) is matched by the producers.
+// LDS: 4 halo buffers [18][18 px x 80 B + 96] + statistics scratch + four transposition tiles = 146 KB.
 //
-// Measured (round 4, tools/pc16_ts.py = s_memtime accumulators per role, [8,.,256,256] 128 -> 128 with residual, cycles per
-// tile; ideal MFMA time 36 steps x 512 = 18.4 k): fragments + MFMA issue 20 k, step barriers 6 k, halo bursts 10 k, output
-// stage 9.5 k -> ~46 k without the probes = 0.40 of the MFMA roof on this shape, the same speed as the all-waves-equal kernel it
-// replaces (conv3x3_halo16_kernel, rounds 2-3: 16 x 16 tile, two blocks per CU), which is why this is a replacement, not a gain:
-//   - VALU work of one wave and MFMA work of another wave on the SAME SIMD do not overlap: spread under the MFMAs, one piece
-//     per step, the GroupNorm + SiLU of a chunk stretched the nine steps by 2 500-3 000 cycles; as one burst with the matrix
-//     pipe idle it takes 2 900 -- 412 cycles per 16-byte piece = 16 transcendentals x 16 cycles + 39 other VALU x 4: the
-//     cost is the instruction time itself (v_exp / v_rcp are quarter rate), not arbitration (s_setprio on either role moves
-//     time between the two accumulators, sum unchanged), not instruction order (stage-by-stage over 24 channel pairs: 2 900
-//     vs 3 300), not the in-order return of HBM loads ahead of weight tiles (a three- vs nine-deep weight ring: no change).
-//   - dword stores from the accumulator layout are store-issue bound (~7 B / cycle / CU: 10 k cycles per tile, 18 k with
-//     the residual loads); 16-byte accesses through the transposition tiles: 8.4 k / 9.5 k.
-// So on gfx950 the floor of this fused op is MFMA time + transform time + output stage ~ 18.4 + 10 + >= 5 k cycles per tile
-// (~0.55 of the roof); what is left above it here: step barriers (6 k) and LDS-write-bound transposition in the output stage.
+// How it got here (round 4; tools/pc16_ts.py = s_memtime accumulators per role against the 100 MHz counter, [8,.,256,256]
+// 128 -> 128 with GroupNorm + SiLU input and residual; ideal MFMA time 8 tiles x 36 steps x 512 = 147 k cycles per block):
+//   weights through three LDS slots, one barrier per step, halo bursts with the consumers parked: ~370 k cycles per block
+//     (the speed of the all-waves-equal kernel of rounds 2-3);
+//   B fragments from L2, one barrier per chunk:                                   338 k
+//   + packed output stage with scalar-offset addressing, early residual requests: 324 k (9.7 k -> 6.4 k per tile's stage)
+//   + one filler per MFMA gap (the compiler's order clumped 4 ds_read + 4 buffer_load + scalar adds behind one MFMA:
+//     41 cycles per MFMA, now 36):                                                 324 k, producers now critical
+//   + SCALAR fp32 in the staging waves: beside an MFMA stream a packed fp32 instruction costs ~20 cycles more than the two
+//     scalar ones it replaces (MI355X_MICROARCH.md) -- 26 k -> 12 k cycles of staging per tile:             265 k = 0.56
+//   What did NOT change anything: per-chunk window arithmetic hoisted / division-free cursors / parameters folded at use /
+//   a fourth halo buffer (the producers' "requests" segment stays ~2 k cycles per chunk: vector-memory issue behind the
+//   consumers' B loads -- B fragments are ~145 KB per chunk and CU through the vector-memory path, half of it the same
+//   lines for the two pixel halves).
+// Wall time moved less than cycles (204 -> 176-190 us): the part clocks itself down as the MFMA duty rises (1.66 GHz at
+// 324 k cycles, 1.41 GHz at 265 k, same shape, different boxes 1.4-2.0 GHz) -- DVFS gives a cycle saving partly back.
 #include "conv_common.h"
 #ifdef FLOWSE_MEASURE
 #include "pc_measure.h"
@@ -53,12 +52,13 @@ namespace flowse {
 namespace {
 constexpr int PC_ROWB = 80;                        // bytes per halo pixel / weight row: 32 x 16 bit + 16 pad (conflict-free b128 reads)
 constexpr int PC_HPITCH = 18 * PC_ROWB + 96;       // halo image row: 1536 B = 0 mod 256
-constexpr int PC_HBUF_X = 32768;                   // pitch of the three halo buffers (18 rows = 27 KB each)
+constexpr int PC_HBUF_X = 18 * PC_HPITCH;            // one halo buffer: 18 rows = 27 KB
+constexpr int PC_NHBUF = 4;                        // halo buffers: the staging runs up to three chunks ahead of the MFMAs
 constexpr int PCF_STEP = 2 * 64 * 16;                // fragment-order weights: bytes of one (32-channel block, chunk, tap) = 2 halves x 1 KB
 constexpr int PCF_CHUNK = 9 * PCF_STEP;
 constexpr int PC_RED = 2 * 2 * 128 * 2 * 4;        // statistics scratch of the output stage: [2 waves][2 sub-tiles][128 ch][mean, M2]
 constexpr int PC_TSCR = 4 * 32 * 68 * 4;             // the consumers' transposition tiles (pc16_out_wide)
-constexpr int PC_LDS = 3 * PC_HBUF_X + PC_RED + PC_TSCR;
+constexpr int PC_LDS = PC_NHBUF * PC_HBUF_X + PC_RED + PC_TSCR;
 constexpr int PC_PIECES = 6;                       // 16-byte halo pieces per producer thread and chunk (324 x 4 / 256)
 
 // position of one (tile, channel block) work item
@@ -69,14 +69,12 @@ struct PcItem {
 
 // ---- output stage of one consumer wave: its 4 x (32 pixels x 64 channels) of accumulators (sub-tile t, row pair i, both
 // channel tiles j) leave through a WAVE-PRIVATE fp32 LDS tile [32 px][64 ch] so that every global access is 16 bytes -- a
-// lane ends up with 8 consecutive channels of one pixel: one dwordx4 residual load and one dwordx4 store per 8 values
-// instead of a dword each.  (halo16_out_direct's dword stores are store-issue bound at ~7 B / cycle / CU: 10 k cycles per
-// 16 x 16 x 128 tile, 18 k with the residual loads, measured with tools/pc16_ts.py -- as long as the 36-step main loop.)
-// LDS traffic per lane and tile: 128 ds_write_b32 + 32 ds_read_b128, in-order per wave: no barrier.  Bias / per-sample
-// bias / residual / scale, ONE rounding to the storage type, and the GroupNorm partial statistics (mean, M2 per
-// channel and 8 x 16 statistics tile) of exactly what was stored: per lane over its 8 pixels of a sub-tile (pivoted),
-// equal-count Chan merges over the 8 lanes that share a channel octet (64 pixels), then with the wave that holds the
-// other 64 pixels through `red` ([2][2][128][2] floats) after ONE block barrier -- which the producers match.
+// lane ends up with 8 consecutive channels of one pixel (dword stores straight from the accumulator layout were store-issue
+// bound at ~7 B / cycle / CU).  LDS traffic per lane and tile: 128 ds_write_b32 + 32 ds_read_b128, in-order per wave: no
+// barrier.  Bias / per-sample bias / residual / scale, ONE rounding to the storage type, and the GroupNorm partial
+// statistics (mean, M2 per channel and 8 x 16 statistics tile) of exactly what was stored: per lane over its 8 pixels of a
+// sub-tile (pivoted), equal-count Chan merges over the 8 lanes that share a channel octet (64 pixels), then with the wave
+// that holds the other 64 pixels through `red` ([2][2][128][2] floats) after ONE block barrier -- which the producers match.
 template <bool F16>
 __device__ __forceinline__ unsigned pc_pack2(float a, float b) {
     return St<typename std::conditional<F16, f16_t, bf16_t>::type>::pack2(a, b);
@@ -214,8 +212,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     using T16 = typename std::conditional<F16, f16_t, bf16_t>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     PC_TS_ENTRY
-    char* Hs = reinterpret_cast<char*>(smem);              // [3][18][PC_HPITCH] at a pitch of PC_HBUF_X
-    float* red = reinterpret_cast<float*>(Hs + 3 * PC_HBUF_X);
+    char* Hs = reinterpret_cast<char*>(smem);              // [PC_NHBUF][18][PC_HPITCH]
+    float* red = reinterpret_cast<float*>(Hs + PC_NHBUF * PC_HBUF_X);
     float* tscr = red + PC_RED / 4;                        // [4 consumer waves][32][PCW_PITCH]
 
     const int tid = threadIdx.x;
@@ -391,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         FLOWSE_PC_LOADA(xa, 0, 0, 0)
         for (int gc = 0; gc < Ctot; ++gc) {
             const bool tile_end = cit == nchunks - 1;
-            const int hnext = hoff == 2 * PC_HBUF_X ? 0 : hoff + PC_HBUF_X;
+            const int hnext = hoff == (PC_NHBUF - 1) * PC_HBUF_X ? 0 : hoff + PC_HBUF_X;
             if (gc > 0) __syncthreads();                   // (X gc) the halos of chunks gc and gc + 1 are in LDS; the producers may
             PC_TS_ADD(1)                                   //        overwrite the buffer of chunk gc - 1.   1: chunk barrier
             FLOWSE_PC_STEP(0) FLOWSE_PC_STEP(1) FLOWSE_PC_STEP(2) FLOWSE_PC_STEP(3) FLOWSE_PC_STEP(4) FLOWSE_PC_STEP(5)
@@ -583,31 +581,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
             if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) + hlds[q]) = RX[q];             \
     }
 
-    // ---- prologue: chunks 0 and 1 -> buffers 0 and 1; raw pieces of chunks 2 and 3 in flight
+    // ---- prologue: chunks 0, 1, 2 -> buffers 0, 1, 2; raw pieces of chunks 3 and 4 in flight
     FLOWSE_PC_HLOAD(ra, hin_a, pa)
     FLOWSE_PC_HLOAD(rb, hin_b, pb)
     FLOWSE_PC_BURST(ra, hin_a, pa, 0)
     FLOWSE_PC_HLOAD(ra, hin_a, pa)
     FLOWSE_PC_BURST(rb, hin_b, pb, PC_HBUF_X)
     FLOWSE_PC_HLOAD(rb, hin_b, pb)
+    FLOWSE_PC_BURST(ra, hin_a, pa, 2 * PC_HBUF_X)
+    FLOWSE_PC_HLOAD(ra, hin_a, pa)
     PC_TS_DECL
     PC_TS_START
     int cit = 0;
-    int hb = 2 * PC_HBUF_X;                                // buffer (byte offset) of chunk gc + 2
+    int hb = 3 * PC_HBUF_X;                                // buffer (byte offset) of chunk gc + 3
     // One chunk interval gc + GO: after the chunk barrier the consumers work on chunk gc + GO and are done with chunk
-    // gc + GO - 1, whose buffer takes chunk gc + GO + 2 (raw pieces RX, requested two intervals ago); then the raw pieces
-    // of chunk gc + GO + 4 are requested into the same registers.  The staging runs a whole chunk ahead of what the next
-    // barrier needs, so the consumers never wait for it unless the producers fall a chunk behind (output stage: the bursts
-    // of the next tile's first two chunks are done before the tile's barrier (S)).
+    // gc + GO - 1, whose buffer takes chunk gc + GO + 3 (raw pieces RX, requested two intervals ago); then the raw pieces
+    // of chunk gc + GO + 5 are requested into the same registers.  The staging runs two chunks ahead of what the next barrier
+    // needs.  (Four buffers instead of three changed nothing measurable: the consumers' ~1 250 cycles per chunk at the barrier
+    // are not a lack of slack -- per chunk the staging waves need as long as the MFMA waves, ~2 000 of their cycles in the
+    // request segment: twelve vector-memory instructions queued behind the consumers' 36 B-fragment loads per wave and
+    // chunk, ~170 KB per chunk through the CU's one vector-memory path.)
 #define FLOWSE_PC_LCHUNK(GO, RX, HINX, Q)                                                                            \
     {                                                                                                                \
         const bool tile_end = cit == nchunks - 1;                                                                    \
         __syncthreads();                                   /* (X gc + GO) */                                        \
         PC_TS_ADD(1)                                       /* 1: chunk barrier */                                   \
-        if (gc + (GO) + 2 < Ctot) { FLOWSE_PC_BURST(RX, HINX, Q, hb) }                                               \
-        hb = hb == 2 * PC_HBUF_X ? 0 : hb + PC_HBUF_X;                                                               \
+        if (gc + (GO) + 3 < Ctot) { FLOWSE_PC_BURST(RX, HINX, Q, hb) }                                               \
+        hb = hb == (PC_NHBUF - 1) * PC_HBUF_X ? 0 : hb + PC_HBUF_X;                                                  \
         PC_TS_ADD(4)                                       /* 4: halo burst */                                      \
-        FLOWSE_PC_HLOAD(RX, HINX, Q)                        /* chunk gc + GO + 4 */                                  \
+        FLOWSE_PC_HLOAD(RX, HINX, Q)                        /* chunk gc + GO + 5 */                                  \
         PC_TS_ADD(0)                                       /* 0: requests */                                        \
         ++cit;                                                                                                       \
         if (tile_end) {                                                                                              \
@@ -617,8 +619,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         }                                                                                                            \
     }
     for (int gc = 0; gc < Ctot; gc += 2) {
-        FLOWSE_PC_LCHUNK(0, ra, hin_a, pa)                 // ra holds chunk gc + 2
-        if (gc + 1 < Ctot) { FLOWSE_PC_LCHUNK(1, rb, hin_b, pb) }             // rb holds chunk gc + 3
+        FLOWSE_PC_LCHUNK(0, rb, hin_b, pb)                 // rb holds chunk gc + 3
+        if (gc + 1 < Ctot) { FLOWSE_PC_LCHUNK(1, ra, hin_a, pa) }             // ra holds chunk gc + 4
     }
 #undef FLOWSE_PC_LCHUNK
 #undef FLOWSE_PC_BURST
