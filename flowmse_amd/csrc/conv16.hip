@@ -2,9 +2,9 @@
 // bf16x3 (split operands, fp32 storage), bf16 and fp16 (BASELINE configs 2 / 4: 16-bit activation storage).
 // Replaces (reference) the same ops as the fp32 kernels: ddpm_conv3x3 / ddpm_conv1x1
 // (flowmse/backbones/ncsnpp_utils/layers.py:100-124) inside ResnetBlockBigGANpp (layerspp.py:245-274).
-//   conv3x3_halo_bf16_kernel   LDS-halo 3x3, per-tap weight tile, two blocks per CU: bf16x3 and the 16-bit launches too small
-//                              for the producer / consumer kernel of conv16_pc.hip (which takes everything from 64 x 64 up
-//                              at batch 8)
+//   conv3x3_halo_bf16_kernel   LDS-halo 3x3, per-tap weight tile, two blocks per CU: the operand modes on fp32 storage
+//                              (bf16x3, bf16 / fp16 on networks the storage modes do not take) and, in the storage modes,
+//                              images whose height is a multiple of 8 but not of 16 (conv16_pc.hip takes the rest)
 //   conv_flat16_kernel         flat 1x1 / small 3x3 on 16-bit activations, split-K with fp32 slabs
 //   convert_kernel             storage conversion at the boundaries; pack_conv_bf16: host-side operand planes
 #include "conv_common.h"
