@@ -428,8 +428,8 @@ int conv16_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     const int64_t tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
     const int stages = ((Cin / KC) * taps + 1) / 2;
     if (tiles >= 256 || stages < 4) return 1;
-    int64_t ks = (512 + tiles - 1) / tiles;
-    if (ks > stages / 2) ks = stages / 2;
+    int64_t ks = (512 + tiles - 1) / tiles;           // (swept in round 4: 128 ... 1024 blocks, 2 / 4 stages per slice: flat,
+    if (ks > stages / 2) ks = stages / 2;             //  profiles/r04_policy_sweep.md)
     if (ks < 1) ks = 1;
     const int per = (int)((stages + ks - 1) / ks);
     return (int)((stages + per - 1) / per);

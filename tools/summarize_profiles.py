@@ -97,6 +97,10 @@ def main(tag):
                     f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.3f}\n")
             f.write(f"fp32 matrix peak at that clock: {64 * 1024 * cyc / dur / 1e3:.1f} TFLOP/s "
                     "(64 FLOP/clk/SIMD x 1024 SIMD)\n")
+            if "SQ_BUSY_CU_CYCLES" in m:
+                cu = m["SQ_BUSY_CU_CYCLES"] / 256.0
+                f.write(f"shader clock from the CUs' own busy cycles (SQ_BUSY_CU_CYCLES / 256 CUs / duration): {cu / dur:.2f} GHz; "
+                        f"MFMA busy fraction per SIMD at that clock: {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cu):.3f}\n")
         print("wrote", os.path.join(P, f"{tag}_pmc_dominant_kernel.txt"))
     sq16 = os.path.join(G, "prof_sq16", f"{tag}_counter_collection.csv")
     if os.path.exists(sq16):                                # SQ counters of the 16-bit producer / consumer conv (bf16 run)
@@ -123,6 +127,12 @@ def main(tag):
                 f.write(f"effective clock (GRBM_GUI_ACTIVE / 8 XCD / duration): {cyc / dur:.2f} GHz\n")
                 f.write("MFMA busy fraction per SIMD (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMD x cycles)): "
                         f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.3f}\n")
+                if "SQ_BUSY_CU_CYCLES" in m:
+                    cu = m["SQ_BUSY_CU_CYCLES"] / 256.0
+                    f.write(f"shader clock from the CUs' own busy cycles (SQ_BUSY_CU_CYCLES / 256 CUs / duration): {cu / dur:.2f} GHz; "
+                            f"MFMA busy fraction per SIMD at that clock: {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cu):.3f}\n"
+                            "# (s_memtime inside the kernel agrees with the second clock: 1.4-1.7 GHz against the 100 MHz counter, "
+                            "tools/pc16_ts.py -- the part clocks this kernel down; GRBM_GUI_ACTIVE does not follow it)\n")
             print("wrote", os.path.join(P, f"{tag}_pmc_bf16_kernel.txt"))
     for k in dom:
         print(k, out[k])
