@@ -406,7 +406,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
                 pit = item_at(min(kitem, n_items - 1));
                 set_out();
                 PC_TS_ADD(3)                               // 3: output stage
-                FLOWSE_PC_WLOAD(0, wnext, 0) FLOWSE_PC_WLOAD(1, wnext, 1) FLOWSE_PC_WLOAD(2, wnext, 2)
+                if (has_res) {                             // (without a residual the ring still holds the refills of taps 6-8:
+                    FLOWSE_PC_WLOAD(0, wnext, 0) FLOWSE_PC_WLOAD(1, wnext, 1) FLOWSE_PC_WLOAD(2, wnext, 2)     //  the next tile's steps 0-2)
+                }
                 FLOWSE_PC_LOADA(xa, hnext, 0, 0)           // (in LDS since the barrier of the finished chunk; a stale read after the last tile is never used)
             }
             hoff = hnext;
