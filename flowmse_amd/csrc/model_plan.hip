@@ -343,6 +343,30 @@ struct Builder {
         return o;
     }
 
+    // A deferred split-K conv whose consumer turned out not to run a two-pass reduction after all: its own reduction launch
+    Tn reduce_deferred(SkPartial& sp, int H, int Wd, int Cout) {
+        flowse_model* M = m;
+        Tn o = alloc(H, Wd, Cout);
+        const size_t part = sp.part_off, o_off = o.off;
+        const int ks = sp.ks, Bn = B, odt = o.dt;
+        const int64_t bias = sp.bias;
+        op("splitk_reduce@" + std::to_string(H) + "x" + std::to_string(Wd), [=](hipStream_t s) {
+            ConvArgs c;
+            c.B = Bn; c.H = H; c.W = Wd; c.Cout = Cout; c.C1 = Cout; c.taps = 1;
+            c.scale = 1.f;
+            c.ksplit = ks;
+            c.partial = M->A(part);
+            c.bias = bias >= 0 ? M->W(bias) : nullptr;
+            c.out = M->A(o_off);
+            c.in_dt = odt;
+            c.out_dt = odt;
+            return launch_splitk_reduce(c, s);
+        }, 0.0, 4.0 * ks * (double)Bn * H * Wd * Cout + (double)dt_size(odt) * Bn * H * Wd * Cout);
+        arena.release(sp.part_off);
+        sp.valid = false;
+        return o;
+    }
+
     // ResnetBlockBigGANpp.forward, layerspp.py:245-274
     Tn resblock(const Module& mod, const Tn& x1, const Tn* x2) {
         const float rs2 = 0.70710678118654752440f;
@@ -398,6 +422,16 @@ struct Builder {
             release(xr);
         }
         Tn out;
+        // The two fusions above were requested from PREDICTED shapes / types; Conv_1 is decided from the tensors that exist:
+        //  * the shortcut's slices can only ride on Conv_1's reduction if Conv_1 itself runs split -- else they get their
+        //    own reduction launch now;
+        //  * per-channel mean / scale from Conv_0's reduction are only of use to a Conv_1 that normalises on load -- else
+        //    they are released and GroupNorm_1 is materialised below.
+        if (sp.valid && !sk_two_pass(h1.dt, h1.H, h1.W, h1.C, mod.out_ch, 9)) xs = reduce_deferred(sp, h1.H, h1.W, mod.out_ch);
+        if (gf.done && !gf.apply && !fusable(h1, 0)) {
+            gn_release(gf.g);
+            gf.done = false;
+        }
         const Tn* resid = sp.valid ? nullptr : (xs.valid() ? &xs : &x1);
         const SkPartial* extra = sp.valid ? &sp : nullptr;
         if (gf.done && gf.apply) {                       // h1 already is act(GroupNorm_1(Conv_0(.)))
