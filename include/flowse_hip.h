@@ -214,9 +214,10 @@ int flowse_op_conv2d(const float* in1, int C1, const float* in2, int C2, const f
 int64_t flowse_op_conv2d_scratch_floats(int B, int H, int W, int Cin, int Cout, int taps);
 /* The same contract on the 16-bit matrix cores with 16-bit activation storage (BASELINE configs 3 / 5; dt 1 = bf16,
  * 2 = IEEE half): the fp32 tensors are rounded to dt on the way in, the conv runs as in the 16-bit modes of the model
- * handle (LDS-halo kernel for 3x3 shapes it covers, flat kernel (+ split-K) otherwise), the result is widened back.
+ * handle (producer / consumer LDS-halo kernel for the 3x3 shapes it covers -- its fragment-order copy of the weights is
+ * made here per call --, per-tap halo kernel or flat kernel (+ split-K) otherwise), the result is widened back.
  * Optional fused GroupNorm(+SiLU) of the input from per-(sample, channel) gn_mean / gn_scale [B][C1+C2] and gn_beta
- * [C1+C2] (LDS-halo shapes only).  `scratch`: device memory, >= 2*(in + w + res + 2*out elements) + 4*ksplit*out
+ * [C1+C2] (LDS-halo shapes only).  `scratch`: device memory, >= 2*(in + 2*w + res + 2*out elements) + 4*ksplit*out
  * elements + 4 KB bytes. */
 int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
                         const float* res, const float* gn_mean, const float* gn_scale, const float* gn_beta, int silu,
