@@ -55,6 +55,36 @@ __device__ __forceinline__ GnQuad gn_quad(const GnParams& gn, int silu, int b, i
 // branch resamples act(GroupNorm(x)), layerspp.py:251-259): both from one read of the input.
 constexpr int FIR_CC = 32;                 // channels per block
 
+// Stage the input window of a block into LDS (fused GroupNorm(+SiLU) on the way in; `raw` also takes the untransformed
+// values).  ALL of a thread's pixels are requested before the first one is used: the plain loop (load -> transform -> store
+// per pixel, five or six dependent round trips per thread) made both kernels latency-bound -- the 16-bit modes, with half
+// the bytes, were no faster than fp32 (fir_down at 256 x 256: 91 us vs 99 us).
+template <class ST, int NPX, int IX>
+__device__ __forceinline__ void fir_stage(float (*tile)[FIR_CC], float (*raw)[FIR_CC], const ST* base, const GnQuad& g, int pl,
+                                          int q, int iy0, int ix0, int H, int W, int C, bool cok) {
+    constexpr int NIT = (NPX + 31) / 32;
+    float4 r[NIT];
+    bool in[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int p = pl + 32 * k;
+        const int py = p / IX, px = p - py * IX;
+        const int y = iy0 + py, x = ix0 + px;
+        in[k] = cok && p < NPX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        r[k] = St<ST>::ld4(base + (in[k] ? ((int64_t)y * W + x) * C : 0));          // (clamped address: unconditional load)
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int p = pl + 32 * k;
+        if (p >= NPX) break;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 rv = in[k] ? r[k] : z;
+        const float4 v = in[k] ? apply_tx(rv, g) : z;
+        *reinterpret_cast<float4*>(&tile[p][q * 4]) = v;
+        if (raw) *reinterpret_cast<float4*>(&raw[p][q * 4]) = rv;
+    }
+}
+
 // down: output tile 4 x 8, input window 10 x 18.  grid (tiles_x * tiles_y, ceil(C / 32), B)
 template <class ST>
 __global__ __launch_bounds__(256) void fir_down_kernel(const ST* __restrict__ in, int H, int W, int C, GnParams gn,
@@ -71,17 +101,7 @@ __global__ __launch_bounds__(256) void fir_down_kernel(const ST* __restrict__ in
     const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
     const GnQuad g = cok ? gn_quad(gn, silu, b, C, c) : GnQuad{};
     const ST* base = in + (int64_t)b * H * W * C + (cok ? c : 0);
-    for (int p = pl; p < NPX; p += 32) {
-        const int py = p / IX, px = p - py * IX;
-        const int y = iy0 + py, x = ix0 + px;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f), v = r;
-        if (cok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
-            r = St<ST>::ld4(base + ((int64_t)y * W + x) * C);
-            v = apply_tx(r, g);
-        }
-        *reinterpret_cast<float4*>(&tile[0][p][q * 4]) = v;
-        if (out2) *reinterpret_cast<float4*>(&tile[1][p][q * 4]) = r;
-    }
+    fir_stage<ST, NPX, IX>(tile[0], out2 ? tile[1] : nullptr, base, g, pl, q, iy0, ix0, H, W, C, cok);
     __syncthreads();
     const int oyl = pl >> 3, oxl = pl & 7;                                   // 32 pixel lanes = the 4 x 8 outputs
     const int oy = oy0 + oyl, ox = ox0 + oxl;
@@ -124,17 +144,7 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const ST* __restrict__ in, 
     const int iy0 = ty * TY - 1, ix0 = tx * TX - 1;
     const GnQuad g = cok ? gn_quad(gn, silu, b, C, c) : GnQuad{};
     const ST* base = in + (int64_t)b * H * W * C + (cok ? c : 0);
-    for (int p = pl; p < NPX; p += 32) {
-        const int py = p / IX, px = p - py * IX;
-        const int y = iy0 + py, x = ix0 + px;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f), v = r;
-        if (cok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
-            r = St<ST>::ld4(base + ((int64_t)y * W + x) * C);
-            v = apply_tx(r, g);
-        }
-        *reinterpret_cast<float4*>(&tile[0][p][q * 4]) = v;
-        if (out2) *reinterpret_cast<float4*>(&tile[1][p][q * 4]) = r;
-    }
+    fir_stage<ST, NPX, IX>(tile[0], out2 ? tile[1] : nullptr, base, g, pl, q, iy0, ix0, H, W, C, cok);
     __syncthreads();
     if (!cok) return;
     // per axis: two taps (position, weight); even o = 2a: (a-1, 1), (a, 3); odd o = 2a+1: (a, 3), (a+1, 1)
