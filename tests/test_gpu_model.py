@@ -329,10 +329,11 @@ def test_precision_modes_vs_oracle(full, mode, bound):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode,bound", [("bf16", 8e-3), ("fp16", 8e-4)])
+@pytest.mark.parametrize("mode,bound", [("bf16", 8e-3), ("fp16", 8e-4), ("bf16x3", 5e-5)])
 def test_16bit_sampler_vs_oracle(full, mode, bound):
     """BASELINE config 3 (bf16) / config 5 (fp16) arithmetic end to end: N = 5 Euler sampler at [2,1,256,128] with
-    activations stored in 16 bits, against the fp32 CPU oracle.  The 1e-3 bar of north_star is stated for fp32; 16-bit
+    activations stored in 16 bits, against the fp32 CPU oracle (and the split-operand mode bf16x3 on fp32 storage: fp32
+    class, measured 5e-6).  The 1e-3 bar of north_star is stated for fp32; 16-bit
     storage over ~110 layers cannot meet it ('hard parts') -- the measured error is printed and bounded at
     about 2x the measured value (bf16 3.9e-3, half 3.9e-4), so a 10x accuracy regression cannot pass."""
     from flowmse_amd.sampling import get_white_box_solver
