@@ -405,13 +405,37 @@ __device__ __forceinline__ void conv3x3_f43_body(const ConvArgs& a, float* smem,
     // instead of one (this schedule) did NOT recover it (447 vs 447 us): the wait is not a fixed latency one can cover
     // with 3 000 cycles but the tail of the HBM round trips of the 8 load batches a block issues per chunk, which gates
     // the chunk barrier. 
+    // The next k-block's operand requests ride in the gaps of this block's first two MFMA groups, ONE per MFMA (five
+    // ds_read_b128 behind group x, 3 TN buffer loads behind group y) instead of as one clump ahead of group x: 432 -> 427 us on
+    // the dominant instantiation (A-B on one box, three runs each).
+#define FLOWSE_WM1(V, BF, K, c, j)                                                                                   \
+    acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[((c) == 0 && CH == 1) ? 4 : (c)].K, BF[c][j].K, acc[c][j], 0, 0, 0);
 #define FLOWSE_WPHASE(V, BF, NKX, NJ, NCHK, DN, BFN, XQ, HL)                                                         \
-    FLOWSE_WLOADA(NKX, NJ, DN) FLOWSE_WLOADB(NKX, NJ, NCHK, BFN)                                                     \
+    {                                                                                                                \
+        const float* Ha = Hcur + abase + (NKX) * LDS_ROW + (NJ) * 8;                                                 \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int j = 0; j < TN; ++j) {               \
+            FLOWSE_WM1(V, BF, x, c, j)                                                                               \
+            FLOWSE_FENCE                                                                                             \
+            _Pragma("unroll") for (int r = (c * TN + j) * 5 / (3 * TN); r < (c * TN + j + 1) * 5 / (3 * TN); ++r)    \
+                DN[r] = *reinterpret_cast<const float4*>(Ha + r * F43_HROW);                                         \
+            FLOWSE_FENCE                                                                                             \
+        }                                                                                                            \
+    }                                                                                                                \
+    if (GN && (XQ) >= 0) xform1((XQ) < 0 ? 0 : (XQ));                                                                \
+    FLOWSE_FENCE                                                                                                     \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int j = 0; j < TN; ++j) {                   \
+        FLOWSE_WM1(V, BF, y, c, j)                                                                                   \
+        FLOWSE_FENCE                                                                                                 \
+        {                                                                                                            \
+            const unsigned so = (wslice + (unsigned)(3 * j + (NKX)) * (unsigned)nchunks + (unsigned)(NCHK)) * 24576u; \
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, wvo + (c * 4 + (NJ)) * 1024, so, 0);        \
+            BFN[c][j] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z),               \
+                                    __uint_as_float(t.w));                                                           \
+        }                                                                                                            \
+        FLOWSE_FENCE                                                                                                 \
+    }                                                                                                                \
     if ((HL) >= 0) gloadH(stile, cnext, (HL) < 0 ? 0 : (HL));                                                        \
     FLOWSE_FENCE                                                                                                     \
-    FLOWSE_WMMA3(V, BF, x) FLOWSE_FENCE                                                                              \
-    if (GN && (XQ) >= 0) xform1((XQ) < 0 ? 0 : (XQ));                                                                \
-    FLOWSE_FENCE FLOWSE_WMMA3(V, BF, y) FLOWSE_FENCE                                                                 \
     FLOWSE_WXA(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, z) FLOWSE_FENCE                                                  \
     FLOWSE_WXB(DN) FLOWSE_FENCE FLOWSE_WMMA3(V, BF, w) FLOWSE_FENCE
 
