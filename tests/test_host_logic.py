@@ -383,3 +383,11 @@ def test_missing_library_fails_loudly(tmp_path):
     copy.write_text(src)                      # same module, but its directory holds no .so
     r = subprocess.run([sys.executable, "-c", code, str(copy)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "IMPORTERROR" in r.stdout and "no CPU fallback" in r.stdout, r.stdout + r.stderr
+
+
+def test_graft_entry_build_passes():
+    """The driver's build check (`__graft_entry__.build()`): compiles (a no-op when the in-tree library is current) and
+    asserts the loaded library's ABI version against include/flowse_hip.h -- a stale literal there would fail every round's
+    build check while all other tests stay green."""
+    import __graft_entry__ as g
+    g.build()
