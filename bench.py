@@ -256,6 +256,82 @@ def run_vbdmd(args, model, dev, world, rank, backend, share, share_of=None):
     }
 
 
+def n1_full_set_reference():
+    """The committed 1-GPU full-set figure of the config[3] workload (profiles/rNN_vbdmd_1gpu_line.json, written by
+    `python bench.py --workload vbdmd` on one MI355X), for `vs_N1_full_set` in a multi-GPU line."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_vbdmd_1gpu_line.json")))
+    if not files:
+        return None
+    j = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    return {"value": j["value"], "ms_per_step": j["ms_per_step"], "utterances": j["config"]["utterances"],
+            "source": f"profiles/{os.path.basename(files[-1])} (the builder's 1-GPU run of the same workload, not measured "
+                      "in this run)"}
+
+
+def rank0_tail_probe(dev, world_of, max_batch, n=None):
+    """Rank 0's device -> host tail of the config[3] gather at `world_of` ranks, measured on ONE GPU: the received slabs
+    of every length bucket are faked on the device (same shapes and row tables as the real exchange) and drained through
+    the product's own _HostDrain -- first call (allocates + page-locks the staging buffer), second call (reuses it) --
+    next to the round-4 form (fresh pin_memory() per call + a .clone() per row) for the before/after."""
+    from flowmse_amd import parallel as P
+    n = n or VBDMD_UTTS
+    true_len, padded, plan, _ = vbdmd_plan(n, world_of, max_batch)
+    F = 256
+    buckets = {}
+    for r in range(world_of):
+        for T, ids in plan[r]:
+            for i in ids:
+                buckets.setdefault(padded[i], [[] for _ in range(world_of)])[r].append((i, true_len[i]))
+    slabs = {}
+    for Tp, per_rank in buckets.items():
+        kmax = max(len(v) for v in per_rank)
+        slabs[Tp] = [torch.zeros((kmax, F, Tp, 2), dtype=torch.float32, device=dev) for _ in range(world_of)]
+    total = sum(F * t * 2 for t in true_len)
+    torch.cuda.synchronize()
+
+    def product():
+        t0 = time.perf_counter()
+        out = [None] * n
+        d = P._HostDrain(F, total, dev)
+        for Tp in sorted(buckets, reverse=True):
+            d.add([(slabs[Tp][r][row], i, t) for r in range(world_of) for row, (i, t) in enumerate(buckets[Tp][r])])
+        d.finish(out)
+        return 1e3 * (time.perf_counter() - t0), out
+
+    def round4():
+        t0 = time.perf_counter()
+        stage = torch.empty(total, dtype=torch.float32).pin_memory()
+        off, views, out = 0, [], [None] * n
+        for Tp in sorted(buckets, reverse=True):
+            for r in range(world_of):
+                for row, (i, t) in enumerate(buckets[Tp][r]):
+                    v = stage[off:off + F * t * 2].view(F, t, 2)
+                    v.copy_(slabs[Tp][r][row, :, :t], non_blocking=True)
+                    views.append((i, v))
+                    off += F * t * 2
+        torch.cuda.current_stream().synchronize()
+        for i, v in views:
+            out[i] = torch.view_as_complex(v.clone())
+        return 1e3 * (time.perf_counter() - t0)
+
+    first, out = product()
+    del out
+    second, out = product()
+    del out
+    third, out = product()
+    ok = all(o is not None and o.shape == (F, true_len[i]) for i, o in enumerate(out))
+    del out
+    before = [round4(), round4()]
+    return {"world_of": world_of, "utterances": n, "payload_MB": round(total * 4 / 1e6, 1),
+            "product_ms": {"first_call_allocates_and_pins": round(first, 2), "second_call": round(second, 2),
+                           "third_call": round(third, 2)},
+            "round4_form_ms": [round(b, 2) for b in before], "rows_ok": ok,
+            "staging_pool": dict(zip(("buffers", "bytes"), P.stage_pool_stats())),
+            "note": "device -> host copies + host bookkeeping of rank 0 after the last gather, fake received slabs of the "
+                    f"{world_of}-rank config[3] partition resident on one GPU; the RCCL gathers themselves are not in it"}
+
+
 def launch_mode(graph_launches):
     return ("hipGraph replay (FLOWSE_GRAPH=1): one graph launch per network evaluation" if graph_launches > 0 else
             "eager launches of the per-shape launch list (the library's default)")
@@ -320,6 +396,8 @@ def main():
                     help="config1: BASELINE config[1] (one [batch,1,256,frames] batch per GPU, weak scaling; the default); "
                          "vbdmd: BASELINE config[3] (ragged utterance set sharded over the GPUs, strong scaling)")
     ap.add_argument("--utts", type=int, default=VBDMD_UTTS, help="--workload vbdmd: number of utterances")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="world > 1: skip the strong-scaling config[3] pass that is otherwise run after the timed region")
     ap.add_argument("--plan", action="store_true",
                     help="--workload vbdmd: print the partition over --gpus ranks (host only, no GPU needed) and exit")
     args = ap.parse_args()
@@ -465,6 +543,13 @@ def main():
         "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
         "achieved_TFLOPs_whole_path": value * nfe_per_step * FLOP_PER_FRAME_NFE / world / 1e12,
     }
+    vb_strong = None
+    if world > 1 and args.solver == "euler" and not args.no_strong:
+        # The weak-scaling number above is ~N x by construction; the workload that shows what N GPUs buy is BASELINE
+        # config[3]: the whole ragged set (fixed total work) dealt to the ranks, one final RCCL gather to rank 0.
+        a3 = argparse.Namespace(**vars(args))
+        a3.steps, a3.warmup = 1, 2
+        vb_strong = run_vbdmd(a3, model, dev, world, rank, backend, share)        # every rank takes part (collectives)
     if rank == 0:
         dom = prof.get("dominant_conv3x3")
         if dom and dom["ms"] > 0:
@@ -617,6 +702,14 @@ def main():
             out["alt_workloads"] = {"vbdmd_one_gpu_share": {k: vb[k] for k in ("value", "unit", "ms_per_step", "config",
                                                                               "frames_value_counts", "plan", "per_rank")}}
             out["alt_workloads"]["vbdmd_one_gpu_share"]["vs_headline_rate"] = vb["value"] / value
+            out["alt_workloads"]["vbdmd_rank0_tail_probe"] = rank0_tail_probe(dev, 8, args.batch)
+        if vb_strong is not None:
+            ref1 = n1_full_set_reference() if (args.utts, args.batch, NS, args.precision) == (VBDMD_UTTS, 8, 5, "fp32") else None
+            vs = {k: vb_strong[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "frames_value_counts", "plan",
+                                           "per_rank")}
+            vs["n1_full_set_reference"] = ref1
+            vs["vs_N1_full_set"] = (vb_strong["value"] / ref1["value"]) if ref1 else None
+            out.setdefault("alt_workloads", {})["vbdmd_strong"] = vs
         if world == 1 and not args.no_cpu_baseline:
             want_oracle = args.solver == "euler" and T <= 256        # 1 utterance x N NFE of the CPU oracle: ~10 s at T = 256
             x_or, out["cpu_baseline"] = cpu_baseline(sd, NS, T, args.cpu_reps, oracle_utt=(rank * B) if want_oracle else None)

@@ -150,22 +150,29 @@ class NCSNpp(nn.Module):
     # ------------------------------------------------------------------ weights -> library
     def _params_in_order(self):
         """Parameter objects in the library's table order.  The list is cached (no module-tree walk per call) and
-        rebuilt whenever ANY parameter object was replaced (``_apply`` with tensor swapping, ``register_parameter``,
-        direct assignment, parametrize / prune, ...): the cache is validated by identity against the owning modules'
-        ``_parameters`` dicts -- one dict lookup per parameter, the same order of work as the version scan."""
+        rebuilt whenever a parameter object OR a submodule on the way to one was replaced (``_apply`` with tensor
+        swapping, ``register_parameter``, direct assignment, parametrize / prune, ``dnn.output_layer = ...``, swapping an
+        entry of ``all_modules``): the cache is validated by identity -- every link ``parent._modules[name] is child``
+        of the module tree and every ``owner._parameters[leaf] is p`` -- a dict lookup each, the same order of work as
+        the version scan."""
         cached = self.__dict__.get("_plist")
         if cached is not None:
-            plist, owners = cached
-            if all(o[0].get(o[1]) is q for o, q in zip(owners, plist)):
+            plist, owners, links = cached
+            if all(d.get(k) is m for d, k, m in links) and all(o[0].get(o[1]) is q for o, q in zip(owners, plist)):
                 return plist
         mods = dict(self.named_modules())
+        links = []
+        for name, m in mods.items():
+            if name:
+                parent, _, key = name.rpartition(".")
+                links.append((mods[parent]._modules, key, m))
         plist, owners = [], []
         for n in self._param_names:
             mod_name, _, leaf = n.rpartition(".")
             m = mods[mod_name]
             owners.append((m._parameters, leaf))
             plist.append(m._parameters[leaf])
-        self.__dict__["_plist"] = (plist, owners)
+        self.__dict__["_plist"] = (plist, owners, links)
         return plist
 
     def canonical_blob(self):
@@ -206,13 +213,26 @@ class NCSNpp(nn.Module):
         The per-call scan of all 647 ``Parameter._version`` counters then runs once instead of once per network
         evaluation -- the per-NFE host cost of the plugin solver loop and of the black-box RK45 right-hand side.
         Explicit invalidation (``mark_dirty``, ``load_state_dict``, ``.to()``, ``set_precision``, the EMA swap of
-        ``VFModel.eval``) is still honoured inside the block."""
+        ``VFModel.eval``) is still honoured inside the block.  The solver loops of ``flowmse_amd.sampling`` (plugin
+        ``update_fn`` loop, black-box RK45 right-hand side) enter this block for every VF_fn that offers it -- an
+        ``update_fn`` that changes parameters in place during sampling must call ``mark_dirty()`` itself; a violation is
+        detected on leaving the block (warning + re-upload on the next call), not inside it."""
         self._frozen_depth += 1
         self._frozen_checked = False
         try:
             yield self
         finally:
             self._frozen_depth -= 1
+            # the promise is checked once on the way out: an in-place parameter update inside the block (test-time
+            # adaptation in a plugin update_fn, ...) was NOT seen by the evaluations after the first one
+            if self._frozen_depth == 0 and self._uploaded_versions is not None and \
+                    self._uploaded_versions != [p._version for p in self._params_in_order()]:
+                self.mark_dirty()
+                import warnings
+                warnings.warn("NCSNpp.weights_frozen(): parameters were modified in place inside the block; the network "
+                              "evaluations after the first one of this block used the weights uploaded before the change "
+                              "(they are re-uploaded on the next call). Do not mutate parameters inside a sampler loop, or "
+                              "call dnn.mark_dirty() after each change.", RuntimeWarning, stacklevel=3)
             self._frozen_checked = False
 
     def _apply(self, fn, *a, **k):

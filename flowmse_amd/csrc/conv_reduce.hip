@@ -225,8 +225,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(ConvArgs a, const
 int launch_splitk_reduce_gn(const ConvArgs& a, const float* gamma, const float* beta, float eps, int silu, int apply,
                             float* gn_mean, float* gn_scale, hipStream_t s) {
     const int HW = a.H * a.W;
-    if (!a.partial || a.ksplit < 1 || a.res || !conv_reduce_gn_ok(a.B, HW, a.Cout) || !gamma || (apply && !beta) ||
-        (!apply && (!gn_mean || !gn_scale))) {
+    // (the kernel sums ONE set of slices and adds neither a residual nor the shortcut's partial set / bias: reject them
+    // instead of dropping their contribution silently)
+    if (!a.partial || a.ksplit < 1 || a.res || a.partial2 || a.ksplit2 || a.bias_x ||
+        !conv_reduce_gn_ok(a.B, HW, a.Cout) || !gamma || (apply && !beta) || (!apply && (!gn_mean || !gn_scale))) {
         set_error("splitk_reduce_gn: unsupported arguments (HW=%d Cout=%d ksplit=%d)", HW, a.Cout, a.ksplit);
         return ERR_ARG;
     }

@@ -873,9 +873,12 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
     const bool halo = conv16_uses_halo(B, H, W, C1, C2, Cout, taps);
     const int ks = halo ? 1 : conv16_ksplit(B, H, W, (int)C, Cout, taps);
     const int64_t nw = ((int64_t)Cout * taps * C + 3) & ~(int64_t)3;
-    int64_t need = 2 * (M * C1 + M * C2 + 2 * nw + 2 * M * Cout) + 64 + (ks > 1 ? 4 * (int64_t)ks * M * Cout : 0);
-    if (scratch_bytes < need + 512) {
-        set_error("flowse_op_conv2d_16: scratch needs %lld bytes", (long long)(need + 512));
+    // the same 256-byte round-up per sub-buffer as take() below, upper bound over the optional ones
+    auto up = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
+    const int64_t need = up(2 * M * C1) + up(2 * M * C2) + 2 * up(2 * nw) + 2 * up(2 * M * Cout) +
+                         (ks > 1 ? up(4 * (int64_t)ks * M * Cout) : 0);
+    if (scratch_bytes < need) {
+        set_error("flowse_op_conv2d_16: scratch needs %lld bytes", (long long)need);
         return ERR_ARG;
     }
     if (gn_mean && !halo) {

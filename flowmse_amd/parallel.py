@@ -164,23 +164,105 @@ def _pad_to(t, multiple):
     return ((int(t) + multiple - 1) // multiple) * multiple
 
 
-def gather_spectrograms(local, local_ids, n_total, group=None, pad_multiple=64):
+# ---- rank 0's device -> host tail.  One grow-only page-locked staging buffer per process (page-locking ~0.5 GB per
+# pass cost more than the copies it serves); results are VIEWS into it, so a buffer is only reused once nothing returned
+# from an earlier call references its storage any more (torch's storage use count) -- a caller that keeps two result
+# sets alive simply owns two buffers.
+_STAGE_POOL = []
+
+
+def _storage_free(buf):
+    try:
+        return torch._C._storage_Use_Count(buf.untyped_storage()._cdata) <= 2      # `buf` itself + the temporary
+    except Exception:                                                                # API moved: never alias, allocate
+        return False
+
+
+def _acquire_stage(nfloats):
+    """A pinned fp32 buffer of >= nfloats elements that no live tensor views; grown (not shrunk) on demand."""
+    best = None
+    for k, buf in enumerate(_STAGE_POOL):
+        if _storage_free(buf) and (best is None or buf.numel() > _STAGE_POOL[best].numel()):
+            best = k
+    if best is not None and _STAGE_POOL[best].numel() >= nfloats:
+        return _STAGE_POOL[best]
+    if best is not None:
+        del _STAGE_POOL[best]                                      # too small and unreferenced: replace it
+    buf = torch.empty(max(int(nfloats * 1.125), 1), dtype=torch.float32)
+    if torch.cuda.is_available():                                  # (plain memory in the CPU-only unit test)
+        buf = buf.pin_memory()
+    _STAGE_POOL.append(buf)
+    return buf
+
+
+def stage_pool_stats():
+    """(buffers, total bytes) of the pinned staging pool -- test / bench hook."""
+    return len(_STAGE_POOL), sum(b.numel() * 4 for b in _STAGE_POOL)
+
+
+class _HostDrain:
+    """Rows of device slabs -> one pinned staging buffer, asynchronously on a side stream; one synchronise at the end."""
+
+    def __init__(self, F, rows_total_floats, dev):
+        self.F = F
+        self.stage = _acquire_stage(rows_total_floats)
+        self.off = 0
+        self.views = []
+        self.keep = []                                             # device slabs stay alive until finish()
+        self.side = torch.cuda.Stream(device=dev)
+
+    def add(self, rows):
+        """rows: [(device tensor [F, >= t, 2] fp32, id, t)] that are complete in the CURRENT stream's order."""
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            for src, i, t in rows:
+                n = self.F * t * 2
+                v = self.stage[self.off:self.off + n].view(self.F, t, 2)
+                v.copy_(src[:, :t], non_blocking=True)
+                self.views.append((i, v))
+                self.off += n
+                self.keep.append(src)
+
+    def finish(self, out):
+        self.side.synchronize()
+        self.keep.clear()
+        for i, v in self.views:
+            out[i] = torch.view_as_complex(v)
+        return out
+
+
+def gather_spectrograms(local, local_ids, n_total, group=None, pad_multiple=64, to_host=True):
     """Gather per-utterance complex spectrograms [F, T_i] from all ranks to rank 0.
 
     local: list of complex64 tensors [F, T_i] on this rank's device; local_ids: their global utterance indices.
-    Returns on rank 0 a list of n_total tensors (CPU, each with its own T_i), elsewhere None.
+    Returns on rank 0 a list of n_total tensors (each with its own T_i), elsewhere None.  to_host=True: CPU tensors --
+    on GPUs these are views into a process-wide pinned staging buffer that is recycled once nothing references it (no
+    per-call page-locking, no per-row copy on the host).  to_host=False (RCCL only): the rows stay on rank 0's device as
+    views of the received slabs (the iSTFT runs there anyway); no device -> host traffic at all.
 
     Exchange: (1) one all_gather of the per-rank utterance counts and one of the (id, T_i) tables -- a few hundred
     bytes; (2) per distinct PADDED length (T_i rounded up to `pad_multiple`, i.e. the lengths the sampler batches by)
     one ``dist.gather`` to rank 0 of a [k, F, Tpad] slab, k = the largest count any rank holds at that length.  Only
     rank 0 receives payload: world x k x F x Tpad x 8 bytes per bucket, against the n_max x F x t_max slab an
-    all_gather of one padded buffer would land on EVERY rank."""
+    all_gather of one padded buffer would land on EVERY rank.  Rank 0 starts a bucket's device -> host copies on a side
+    stream as soon as its gather is ordered, so they run under the next bucket's collective."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1:
         out = [None] * n_total
-        for i, s in zip(local_ids, local):
-            out[i] = s.cpu()
+        if not to_host:
+            for i, s in zip(local_ids, local):
+                out[i] = s
+        elif local and local[0].is_cuda:
+            F = local[0].shape[0]
+            drain = _HostDrain(F, sum(F * s.shape[1] * 2 for s in local), local[0].device)
+            drain.add([(torch.view_as_real(s), i, s.shape[1]) for i, s in zip(local_ids, local)])
+            drain.finish(out)
+        else:
+            for i, s in zip(local_ids, local):
+                out[i] = s.cpu()
         return out
     on_gpu = dist.get_backend(group) == "nccl"
     dev = (local[0].device if local else torch.device("cuda", torch.cuda.current_device())) if on_gpu \
@@ -206,7 +288,9 @@ def gather_spectrograms(local, local_ids, n_total, group=None, pad_multiple=64):
             if i >= 0:
                 buckets.setdefault(_pad_to(t, pad_multiple), [[] for _ in range(world)])[r].append((k, i, t))
     out = [None] * n_total if rank == 0 else None
-    pending = []                                                   # rank 0: (per_rank table, received slabs) per bucket
+    drain = None
+    if rank == 0 and on_gpu and to_host:
+        drain = _HostDrain(F, sum(F * t * 2 for tb in tables for i, t in tb if i >= 0), dev)
     for Tp in sorted(buckets, reverse=True):
         per_rank = buckets[Tp]
         kmax = max(len(v) for v in per_rank)
@@ -216,34 +300,22 @@ def gather_spectrograms(local, local_ids, n_total, group=None, pad_multiple=64):
         recv = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
         dist.gather(slab, recv, dst=0, group=group)
         if rank == 0:
-            pending.append((per_rank, recv))
-    if rank == 0:
-        # Device -> host only AFTER the last gather has been enqueued: the copies of one bucket never sit between two
-        # collectives (round 3 copied bucket by bucket, so every RCCL gather waited for the previous bucket's blocking
-        # .cpu()).  On GPUs the rows go into ONE pinned staging buffer with async copies and a single synchronise.
-        rows = [(recv[r], row, i, t) for per_rank, recv in pending for r in range(world)
-                for row, (_, i, t) in enumerate(per_rank[r])]
-        if on_gpu and rows:
-            total = sum(F * t * 2 for _, _, _, t in rows)
-            stage = torch.empty(total, dtype=torch.float32).pin_memory()
-            off = 0
-            views = []
-            for src, row, i, t in rows:
-                v = stage[off:off + F * t * 2].view(F, t, 2)
-                v.copy_(src[row, :, :t], non_blocking=True)
-                views.append((i, v))
-                off += F * t * 2
-            torch.cuda.current_stream().synchronize()
-            for i, v in views:
-                out[i] = torch.view_as_complex(v.clone())
-        else:
-            for src, row, i, t in rows:
-                out[i] = torch.view_as_complex(src[row, :, :t].cpu().contiguous())
+            rows = [(recv[r][row], i, t) for r in range(world) for row, (_, i, t) in enumerate(per_rank[r])]
+            if drain is not None:
+                drain.add(rows)                                    # async, under the next bucket's collective
+            elif on_gpu:                                           # to_host=False: device views of the received slabs
+                for src, i, t in rows:
+                    out[i] = torch.view_as_complex(src[:, :t])
+            else:                                                  # gloo: the slabs are host memory already
+                for src, i, t in rows:
+                    out[i] = torch.view_as_complex(src[:, :t].contiguous())
+    if drain is not None:
+        drain.finish(out)
     return out
 
 
 def enhance_sharded(sample_fn, specs, max_batch=8, group=None, pad_multiple=64, keep_padding=False, stats=None,
-                    promote=False, plan=None):
+                    promote=False, plan=None, to_host=True):
     """Enhance a ragged set of utterances data-parallel over the ranks of `group` (BASELINE config 4; the reference's
     loop over the test set is evaluate.py:97-136, one utterance per sampler call on one GPU).
 
@@ -254,7 +326,7 @@ def enhance_sharded(sample_fn, specs, max_batch=8, group=None, pad_multiple=64, 
     modelled time (plan_shards; `plan` = a precomputed plan_shards() result, e.g. one rank's share of a larger world;
     `promote`: see plan_batches -- off by default because it changes the promoted utterances' results), enhanced and
     gathered to rank 0 with ONE exchange step at the very end (gather_spectrograms).  Returns on rank 0
-    the list of enhanced spectrograms, None elsewhere:
+    the list of enhanced spectrograms (to_host: see gather_spectrograms), None elsewhere:
 
     * keep_padding=False: each cropped back to its own [F, T_i] (the spectrogram of the utterance);
     * keep_padding=True: the whole padded [F, Tpad_i] sample.  This is what the reference feeds to the iSTFT
@@ -286,7 +358,7 @@ def enhance_sharded(sample_fn, specs, max_batch=8, group=None, pad_multiple=64, 
         if torch.cuda.is_available() and out_local and out_local[0].is_cuda:
             torch.cuda.synchronize()
         t1 = time.perf_counter()
-    res = gather_spectrograms(out_local, ids_local, len(specs), group=group, pad_multiple=pad_multiple)
+    res = gather_spectrograms(out_local, ids_local, len(specs), group=group, pad_multiple=pad_multiple, to_host=to_host)
     if stats is not None:
         run = sum(T * len(ids) for T, ids in batches)
         cap = sum(T * max_batch for T, _ in batches)

@@ -114,8 +114,9 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
  *   hi*hi + hi*lo + lo*hi accumulated in fp32 (fp32-class accuracy, ~1e-5 end to end).
  * 2 "bf16" (BASELINE config 3) / 3 "fp16" (BASELINE config 5): 16-bit STORAGE modes -- every wide activation tensor
  *   between kernels is bf16 / IEEE half, all matrix products run on the 16-bit matrix cores (a 16-bit twin of the packed
- *   weights is kept), accumulators, GroupNorm statistics, time-embedding tables, split-K slabs, the 4-channel pyramid
- *   tensors and the interior of the attention blocks stay fp32.  Applies to networks whose wide channel counts are
+ *   weights is kept) -- including the attention core (16-bit q / k / v and P, v_mfma_f32_32x32x16, attention16_kernel)
+ *   -- while accumulators, GroupNorm statistics, the softmax state (running max / sum), time-embedding tables, split-K
+ *   slabs and the 4-channel pyramid tensors stay fp32.  Applies to networks whose wide channel counts are
  *   multiples of 32 (the released configuration); otherwise storage stays fp32 and only the operands of the 3x3 convs
  *   with Cout % 128 == 0 become 16-bit.
  * The boundary tensors (x, y, out: complex64; t: float32) are the same in every mode. */
@@ -187,7 +188,7 @@ int flowse_istft_decompress(const void* spec_c64, int B, int T, int Tpad, float 
  * default) -- reported under the key "dominant_conv3x3"; mode 1: every launch, keyed by op label.  _end synchronises
  * on the recorded events and writes a JSON object {label: {"launches", "ms", "flops", "bytes", "issued"}} into `json`:
  * algorithmic flops / bytes of the bracketed launches, and `issued` = the flops the matrix cores execute for them
- * (Winograd forms issue 1/2 or 2/3 of the algorithmic direct-convolution flops).  The extra key "_all_launches"
+ * (the F(4,3) Winograd form issues 1/2 of the algorithmic direct-convolution flops).  The extra key "_all_launches"
  * totals launches / flops / issued over EVERY launch made between _begin and _end (no timing). */
 int flowse_profile_begin(flowse_model* m, int mode);
 int flowse_profile_end(flowse_model* m, char* json, int cap);
@@ -217,8 +218,9 @@ int64_t flowse_op_conv2d_scratch_floats(int B, int H, int W, int Cin, int Cout, 
  * handle (producer / consumer LDS-halo kernel for the 3x3 shapes it covers -- its fragment-order copy of the weights is
  * made here per call --, per-tap halo kernel or flat kernel (+ split-K) otherwise), the result is widened back.
  * Optional fused GroupNorm(+SiLU) of the input from per-(sample, channel) gn_mean / gn_scale [B][C1+C2] and gn_beta
- * [C1+C2] (LDS-halo shapes only).  `scratch`: device memory, >= 2*(in + 2*w + res + 2*out elements) + 4*ksplit*out
- * elements + 4 KB bytes. */
+ * [C1+C2] (LDS-halo shapes only).  `scratch`: device memory; sufficient for every shape: 2*(in + 2*w + res + out
+ * elements) + 4*ksplit*out elements + 4 KB bytes (each of the up to seven sub-buffers is rounded up to 256 bytes; the
+ * error message of a too-small call states the exact byte count). */
 int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
                         const float* res, const float* gn_mean, const float* gn_scale, const float* gn_beta, int silu,
                         float* out, int B, int H, int W, int Cout, int taps, float scale, int dt, void* scratch,

@@ -58,6 +58,16 @@ def test_facade_state_dict_and_registry():
     blob = m.canonical_blob()
     assert blob.numel() == t["n_params"]
     assert torch.equal(blob[:8], sd["output_layer.weight"].reshape(-1))
+    # the cached parameter list follows a replaced parameter AND a replaced submodule (an orphaned owner must not
+    # keep serving the old tensor): same identity scan as the upload's
+    import copy
+    new_out = copy.deepcopy(m.output_layer)
+    with torch.no_grad():
+        new_out.weight.fill_(0.25)
+    m.output_layer = new_out
+    assert m._params_in_order()[0] is new_out.weight and float(m.canonical_blob()[0]) == 0.25
+    m.output_layer.weight = torch.nn.Parameter(torch.full_like(new_out.weight, 0.5))
+    assert float(m.canonical_blob()[0]) == 0.5
 
 
 def test_unsupported_configs_fail_loudly():
@@ -214,6 +224,27 @@ def test_plan_shards_config3_partition():
     assert (640, [0]) in pr                                  # 512 frames of padding per member: never worth it
     assert plan_batches(range(3), [192, 128, 128], 8, promote=True) == [(192, [0, 1, 2])]
     assert plan_batches(range(3), [192, 128, 128], 8) == [(192, [0]), (128, [1, 2])]
+
+
+def test_gather_staging_buffer_is_reused_not_aliased():
+    """Rank 0's host staging of the final gather (parallel._acquire_stage): two consecutive gathers reuse ONE buffer
+    (no per-call allocation / page-locking) -- unless a result of the first is still alive, which must never be aliased."""
+    from flowmse_amd import parallel as P
+    P._STAGE_POOL.clear()
+    a = P._acquire_stage(1000)
+    res1 = [torch.view_as_complex(a[:64].view(4, 8, 2))]           # what gather_spectrograms hands out: views
+    b = P._acquire_stage(900)
+    assert b is not a and P.stage_pool_stats()[0] == 2             # first result alive: a second buffer
+    del res1
+    c = P._acquire_stage(900)
+    assert (c is a or c is b) and P.stage_pool_stats()[0] == 2     # released: reused, nothing new allocated
+    del b, c
+    d = P._acquire_stage(1000)
+    assert d is a                                                  # the larger free buffer serves it
+    e_id = id(d)
+    del d
+    assert id(P._acquire_stage(10)) == e_id
+    P._STAGE_POOL.clear()
 
 
 def test_fused_sampler_only_for_classes_that_opt_in_themselves():
