@@ -169,6 +169,7 @@ def _pad_to(t, multiple):
 # from an earlier call references its storage any more (torch's storage use count) -- a caller that keeps two result
 # sets alive simply owns two buffers.
 _STAGE_POOL = []
+_SIDE_STREAMS = {}                                                 # device index -> the drain's copy stream
 
 
 def _storage_free(buf):
@@ -209,7 +210,10 @@ class _HostDrain:
         self.off = 0
         self.views = []
         self.keep = []                                             # device slabs stay alive until finish()
-        self.side = torch.cuda.Stream(device=dev)
+        key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        self.side = _SIDE_STREAMS[key]
 
     def add(self, rows):
         """rows: [(device tensor [F, >= t, 2] fp32, id, t)] that are complete in the CURRENT stream's order."""
