@@ -72,6 +72,8 @@ SIGNATURES = {
     "flowse_op_conv3x3_gn": (_i, [_fp, _i, _fp, _i, _fp, _fp, _f, _i, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _fp, _vp]),
     "flowse_op_conv3x3_f43": (_i, [_fp, _i, _fp, _i, _fp, _fp, _f, _i, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _fp, _vp]),
     "flowse_op_conv3x3_f43_scratch_floats": (_i64, [_i, _i, _i, _i, _i]),
+    "flowse_op_conv3x3_w2d": (_i, [_fp, _i, _fp, _i, _fp, _fp, _f, _i, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _fp, _vp]),
+    "flowse_op_conv3x3_w2d_scratch_floats": (_i64, [_i, _i, _i, _i, _i]),
     "flowse_op_group_norm_scratch_floats": (_i64, [_i, _i, _i]),
     "flowse_op_group_norm": (_i, [_fp, _i, _fp, _i, _fp, _fp, _f, _i, _fp, _i, _i, _i, _fp, _vp]),
     "flowse_op_fir_up": (_i, [_fp, _fp, _i, _i, _i, _i, _vp]),

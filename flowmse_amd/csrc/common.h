@@ -263,6 +263,10 @@ struct ConvArgs {
     // optional F(4,3) Winograd weights of a 3x3 conv in MFMA fragment order (launch_f43_weights): when set and the
     // shape qualifies (conv_supports_wino) the fp32 3x3 runs the Winograd kernel (18 transformed taps per channel pair)
     const float* wino = nullptr;
+    // optional F(4,3) x F(2,3) two-dimensional Winograd weights (launch_w2d_weights, 24 transformed taps per channel pair):
+    // when set and the shape qualifies (conv_supports_w2d) the fp32 3x3 runs conv3x3_w2d_kernel -- its fused statistics
+    // come in blocks of 64 pixels (4 x 16 strips: stats_nblk = H W / 64, set by the plan, Builder::conv)
+    const float* wino2 = nullptr;
     // activation storage types (DT_*).  16-bit inputs are taken by the 16-bit matrix-core kernels (halo 3x3 with
     // Cout % 128 == 0, flat 1x1 / small 3x3: `wq` = the [Cout][taps][Cin] weights in the matching 16-bit type, terms = 1)
     // and by the 4-channel heads; 16-bit outputs by those plus the 4-channel input convs, the fp32 flat kernel
@@ -284,6 +288,14 @@ int launch_f43_weights(const float* w_packed, int Cout, int Cin, float* out, hip
 // [Cout][9][Cin] 16-bit weights -> MFMA fragment order for conv3x3_pc16_kernel (same element count)
 int launch_pc16_weights(const void* w16, int Cout, int Cin, void* dst, hipStream_t s);
 inline int64_t conv_wino_numel(int Cout, int Cin) { return (int64_t)Cout * 18 * Cin; }
+// F(4,3) x F(2,3) weight transform, packed [Cout][9][Cin] -> fragment order [Cout/32][h][Cin/32][6][4][64][4], on device
+int launch_w2d_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s);
+inline int64_t conv_w2d_numel(int Cout, int Cin) { return (int64_t)Cout * 24 * Cin; }
+// conv_w2d_shape_ok: the two-dimensional Winograd kernel can run this shape (launch_conv takes it whenever
+// ConvArgs::wino2 is set); conv_supports_w2d: ... and the policy wants it (enough blocks to fill the chip): the plan's test
+bool conv_w2d_shape_ok(int B, int H, int W, int C1, int C2, int Cout, int taps);
+bool conv_supports_w2d(int B, int H, int W, int C1, int C2, int Cout, int taps);
+bool conv_w2d_enabled();                   // FLOWSE_W2D (read once): the model handle keeps the 2-D weights and uses the kernel
 bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // whole-K F(4,3) launches of this shape use 128-channel blocks (conv3x3_f43_kernel<GN, false, 2>)
 bool conv_f43_wide(int B, int H, int W, int Cout);

@@ -5,6 +5,7 @@
 //
 // Kernel families (one translation unit each):
 //   conv_f43.hip      fp32 F(4,3) Winograd 3x3 (production kernel of the fp32 mode)
+//   conv_w2d.hip      fp32 F(4,3) x F(2,3) two-dimensional Winograd 3x3 (large images, whole K)
 //   conv_halo.hip     direct fp32 LDS-halo 3x3, 4-channel heads / input layers
 //   conv_flat.hip     flat fp32 kernels: 1x1, small 3x3, split-K slices
 //   conv_reduce.hip   second pass of split-K launches (+ fused GroupNorm statistics / GroupNorm)
@@ -37,6 +38,9 @@ static const bool g_force_generic = getenv("FLOWSE_FORCE_GENERIC_CONV") != nullp
 static const bool g_no_halo = getenv("FLOWSE_NO_HALO_CONV") != nullptr;
 static const bool g_no_wino = getenv("FLOWSE_NO_WINOGRAD") != nullptr;
 static const bool g_no_wino_policy = g_no_wino || g_no_halo || g_force_generic;
+// FLOWSE_W2D=0 keeps the 1-D F(4,3) kernel everywhere (A-B hook); default: the 2-D kernel where conv_supports_w2d says so
+static const bool g_w2d = !(getenv("FLOWSE_W2D") && getenv("FLOWSE_W2D")[0] == '0');
+bool conv_w2d_enabled() { return g_w2d && !g_no_wino_policy; }
 bool conv_force_generic() { return g_force_generic; }
 
 // Winograd plan for a 3x3 shape: 0 = not a Winograd shape (or too small even when sliced), 1 = the Winograd halo
@@ -104,6 +108,18 @@ bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps)
            ((int64_t)H * W + 2 * W + 2) * (C1 > C2 ? C1 : C2) * 4 < (1LL << 31);
 }
 
+// The two-dimensional form: whole-K launches on images that give every CU at least W2D_MIN_ROUNDS blocks of
+// 16 x 16 pixels x 64 channels (below that the 1-D kernel's smaller tiles fill the chip better).
+static const int g_w2d_min_blocks = getenv("FLOWSE_W2D_MIN_BLOCKS") ? atoi(getenv("FLOWSE_W2D_MIN_BLOCKS")) : 512;
+bool conv_w2d_shape_ok(int B, int H, int W, int C1, int C2, int Cout, int taps) {
+    if (g_no_wino_policy || taps != 9 || (H & 15) || (W & 15) || (C1 % KC) || (C2 % KC) || (Cout % 64) || B < 1) return false;
+    const int64_t cmax = C1 > C2 ? C1 : C2;
+    return (int64_t)Cout * 24 * (C1 + C2) * 4 < (1LL << 31) && ((int64_t)H * W + 2 * W + 2) * cmax * 4 < (1LL << 31);
+}
+bool conv_supports_w2d(int B, int H, int W, int C1, int C2, int Cout, int taps) {
+    return conv_w2d_shape_ok(B, H, W, C1, C2, Cout, taps) && ((int64_t)B * H * W / 256) * (Cout / 64) >= g_w2d_min_blocks;
+}
+
 int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
     if ((a.C1 & 3) || (a.C2 & 3) || (a.Cout & 3) || (a.bias2 && (a.bias2_stride & 3)) || (a.taps != 1 && a.taps != 9) ||
         a.C1 <= 0 || (a.in2 == nullptr && a.C2 != 0)) {
@@ -138,6 +154,13 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
             if (a.terms == 1) return launch_halo16_any(a, s);
             set_error("conv: 16-bit path needs terms = 1 (bf16 / f16) or 3 (bf16 only)");
             return ERR_ARG;
+        }
+        if (a.wino2 && conv_w2d_shape_ok(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
+            if (a.stats && a.stats_nblk != a.H * a.W / 64) {
+                set_error("conv: the 2-D Winograd kernel writes its statistics in blocks of 64 pixels (stats_nblk=%d)", a.stats_nblk);
+                return ERR_ARG;
+            }
+            return launch_w2d(a, s);
         }
         if (a.wino && conv_supports_wino(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) return launch_f43(a, s);
         return launch_halo_fp32(a, s);

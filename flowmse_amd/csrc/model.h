@@ -152,6 +152,9 @@ struct flowse_model {
     float* d_wino = nullptr;               // F(4,3) Winograd weights of the 3x3 convs the Winograd kernel can take
     int64_t d_wino_numel = 0;
     std::map<int64_t, int64_t> wino_of;    // packed weight offset (d_w) -> offset in d_wino
+    float* d_wino2 = nullptr;              // F(4,3) x F(2,3) weights of the same convs (conv3x3_w2d_kernel; FLOWSE_W2D=0: absent)
+    int64_t d_wino2_numel = 0;
+    std::map<int64_t, int64_t> wino2_of;
     char* d_ws = nullptr;                  // activation workspace
     size_t d_ws_bytes = 0;
     float* d_ts = nullptr;                 // [N][B] solver times

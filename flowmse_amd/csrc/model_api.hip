@@ -191,6 +191,9 @@ static void free_device_state(flowse_model* m) {
     if (m->d_w16) (void)hipFree(m->d_w16);
     if (m->d_wfrag) (void)hipFree(m->d_wfrag);
     if (m->d_wino) (void)hipFree(m->d_wino);
+    if (m->d_wino2) (void)hipFree(m->d_wino2);
+    m->d_wino2 = nullptr;
+    m->d_wino2_numel = 0;
     if (m->d_call) (void)hipFree(m->d_call);
     if (m->d_rk) (void)hipFree(m->d_rk);
     m->d_rk = nullptr;
@@ -438,6 +441,30 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
         float* dst = m->d_wino + m->wino_of[r.off];
         const int wrc = launch_f43_weights(m->d_w + r.off, r.Cout, r.Cin, dst, nullptr);
         if (wrc != OK) return wrc;
+    }
+    // F(4,3) x F(2,3) weights of the same convs (the two-dimensional kernel takes the large images)
+    m->wino2_of.clear();
+    if (conv_w2d_enabled()) {
+        int64_t w2_total = 0;
+        for (auto& r : pk.wino) {
+            if ((int64_t)r.Cout * 24 * r.Cin * 4 >= (1LL << 31)) continue;
+            m->wino2_of[r.off] = w2_total;
+            w2_total += (conv_w2d_numel(r.Cout, r.Cin) + 63) & ~(int64_t)63;
+        }
+        if (m->d_wino2 && m->d_wino2_numel < w2_total) {
+            FLOWSE_HIP(hipFree(m->d_wino2));
+            m->d_wino2 = nullptr;
+        }
+        if (!m->d_wino2 && w2_total > 0) {
+            FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_wino2), w2_total * sizeof(float)));
+            m->d_wino2_numel = w2_total;
+        }
+        for (auto& r : pk.wino) {
+            const auto it = m->wino2_of.find(r.off);
+            if (it == m->wino2_of.end()) continue;
+            const int wrc = launch_w2d_weights(m->d_w + r.off, r.Cout, r.Cin, m->d_wino2 + it->second, nullptr);
+            if (wrc != OK) return wrc;
+        }
     }
     FLOWSE_HIP(hipDeviceSynchronize());
     // optional bf16 planes for the 3x3 ResBlock convolutions the halo kernel can take
@@ -800,28 +827,29 @@ int flowse_op_conv3x3_gn(const float* in1, int C1, const float* in2, int C2, con
 static int op_conv3x3_winograd(const float* in1, int C1, const float* in2, int C2, const float* gamma,
                                const float* beta, float eps, int silu, const float* w, const float* bias,
                                const float* bias2, int bias2_stride, const float* res, float* out, int B, int H, int W,
-                               int Cout, float scale, float* scratch, void* stream) {
+                               int Cout, float scale, float* scratch, void* stream, bool two_d = false) {
     if (!in1 || !w || !out || !scratch || (gamma && !beta)) {
         set_error("flowse_op_conv3x3_f43: null argument");
         return ERR_ARG;
     }
     if (!in2) C2 = 0;
-    if (!conv_supports_wino(B, H, W, C1, C2, Cout, 9)) {
-        set_error("flowse_op_conv3x3_f43: shape B=%d H=%d W=%d C=%d+%d Cout=%d not covered by the Winograd kernel", B,
-                  H, W, C1, C2, Cout);
+    if (two_d ? !conv_w2d_shape_ok(B, H, W, C1, C2, Cout, 9) : !conv_supports_wino(B, H, W, C1, C2, Cout, 9)) {
+        set_error("flowse_op_conv3x3_%s: shape B=%d H=%d W=%d C=%d+%d Cout=%d not covered by the Winograd kernel",
+                  two_d ? "w2d" : "f43", B, H, W, C1, C2, Cout);
         return ERR_SHAPE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int C = C1 + C2, HW = H * W;
     float* wf = scratch + flowse_op_group_norm_scratch_floats(B, HW, C);
-    int rc = launch_f43_weights(w, Cout, C, wf, s);
+    int rc = two_d ? launch_w2d_weights(w, Cout, C, wf, s) : launch_f43_weights(w, Cout, C, wf, s);
     if (rc != OK) return rc;
     ConvArgs c;
     c.in1 = in1; c.in2 = in2; c.C1 = C1; c.C2 = C2;
     c.w = w; c.bias = bias; c.bias2 = bias2; c.bias2_stride = bias2_stride; c.res = res; c.out = out;
     c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = 9; c.scale = scale;
-    c.wino = wf;
-    const int ks = conv_ksplit(B, H, W, C, Cout, 9);
+    if (two_d) c.wino2 = wf;
+    else c.wino = wf;
+    const int ks = two_d ? 1 : conv_ksplit(B, H, W, C, Cout, 9);
     if (ks > 1) {                           // same split plan as the model handle uses for this shape
         c.ksplit = ks;
         c.partial = wf + conv_wino_numel(Cout, C);
@@ -846,6 +874,18 @@ int64_t flowse_op_conv3x3_f43_scratch_floats(int B, int H, int W, int C, int Cou
     const int ks = conv_ksplit(B, H, W, C, Cout, 9);                   // > 1: F(4,3) runs split over K (small images)
     return flowse_op_group_norm_scratch_floats(B, H * W, C) + conv_wino_numel(Cout, C) +
            (ks > 1 ? (int64_t)ks * B * H * W * Cout : 0);
+}
+
+int64_t flowse_op_conv3x3_w2d_scratch_floats(int B, int H, int W, int C, int Cout) {
+    return flowse_op_group_norm_scratch_floats(B, H * W, C) + conv_w2d_numel(Cout, C);
+}
+
+int flowse_op_conv3x3_w2d(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
+                          float eps, int silu, const float* w, const float* bias, const float* bias2, int bias2_stride,
+                          const float* res, float* out, int B, int H, int W, int Cout, float scale, float* scratch,
+                          void* stream) {
+    return op_conv3x3_winograd(in1, C1, in2, C2, gamma, beta, eps, silu, w, bias, bias2, bias2_stride, res, out, B, H,
+                               W, Cout, scale, scratch, stream, true);
 }
 
 int flowse_op_conv3x3_f43(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,

@@ -214,6 +214,12 @@ struct Builder {
                                                                                  : conv16_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps))
                              : conv_fused_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps);
         if (cin4 && !out_is_res && C1 == 4 && !has2 && conv_cin4_uses_mfma(Bn, H, Wd, Cout, taps)) st_nblk = H * Wd / 128;
+        // the two-dimensional Winograd kernel takes this launch: statistics in 4 x 16 pixel strips
+        const auto w2_it = M->wino2_of.find(w);
+        const int64_t wino2_off = (!in16 && taps == 9 && !cin4 && ks == 1 && w2_it != M->wino2_of.end() &&
+                                   !(wq_off >= 0 && M->precision != 0) && conv_supports_fused_gn(Bn, H, Wd, C1, C2, Cout, taps) &&
+                                   conv_supports_w2d(Bn, H, Wd, C1, C2, Cout, taps)) ? w2_it->second : -1;
+        if (wino2_off >= 0 && st_nblk > 0) st_nblk = H * Wd / 64;
         if (defer || gnf) st_nblk = 0;                   // no output here / the statistics are finished inside the reduction
         if (st_nblk > 0) {
             o.st_nblk = st_nblk;
@@ -275,6 +281,7 @@ struct Builder {
                 c.wq_f16 = M->precision == 3 ? 1 : 0;
             }
             if (wino_off >= 0) c.wino = M->d_wino + wino_off;
+            if (wino2_off >= 0) c.wino2 = M->d_wino2 + wino2_off;
             return c;
         };
         const double flops = 2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2);
@@ -285,8 +292,8 @@ struct Builder {
             const ConvArgs c = make_args();
             return cin4 ? launch_conv_cin4(c, s) : launch_conv(c, s, false);
         }, flops, in_bytes + (ks > 1 ? part_bytes : out_bytes),
-           has_gin && Cout > 64 && ks == 1 && (wino_off < 0 || conv_f43_wide(Bn, H, Wd, Cout)),
-           wino_off >= 0 ? flops * 0.5 : (use_bf16 && terms == 3) ? 3.0 * flops : flops);
+           has_gin && Cout > 64 && ks == 1 && (wino2_off >= 0 || wino_off < 0 || conv_f43_wide(Bn, H, Wd, Cout)),
+           wino2_off >= 0 ? flops / 3.0 : wino_off >= 0 ? flops * 0.5 : (use_bf16 && terms == 3) ? 3.0 * flops : flops);
         if (defer) {                                     // the consumer's reduction sums these slices (ConvArgs::partial2)
             defer->part_off = part_off;
             defer->ks = ks;

@@ -127,8 +127,9 @@ def conv3x3_gn(x1, gamma, beta, w, bias=None, x2=None, bias2=None, res=None, sca
 
 
 def conv3x3_f43(x1, w, gamma=None, beta=None, bias=None, x2=None, bias2=None, res=None, scale=1.0, silu=True,
-                eps=1e-6):
-    """Same contract as conv3x3_gn (gamma None: no normalisation) through the F(4,3) Winograd kernel."""
+                eps=1e-6, form="f43"):
+    """Same contract as conv3x3_gn (gamma None: no normalisation) through the F(4,3) Winograd kernel (form "f43") or the
+    two-dimensional F(4,3) x F(2,3) kernel (form "w2d")."""
     Cout, Cin, k, _ = w.shape
     a1 = nhwc(x1)
     a2 = nhwc(x2) if x2 is not None else None
@@ -140,9 +141,9 @@ def conv3x3_f43(x1, w, gamma=None, beta=None, bias=None, x2=None, bias2=None, re
     rr = nhwc(res) if res is not None else None
     g = gamma.cuda().contiguous() if gamma is not None else None
     be = beta.cuda().contiguous() if beta is not None else None
-    scratch = torch.empty(L.flowse_op_conv3x3_f43_scratch_floats(B, H, W, C1 + C2, Cout), device="cuda")
+    scratch = torch.empty(getattr(L, f"flowse_op_conv3x3_{form}_scratch_floats")(B, H, W, C1 + C2, Cout), device="cuda")
     out = torch.empty(B, H, W, Cout, device="cuda")
-    fn = L.flowse_op_conv3x3_f43
+    fn = getattr(L, f"flowse_op_conv3x3_{form}")
     _lib.check(fn(_lib.ptr(a1), C1, _lib.ptr(a2), C2, _lib.ptr(g), _lib.ptr(be), eps, int(silu),
                                        _lib.ptr(wp), _lib.ptr(bb), _lib.ptr(b2),
                                        b2.shape[1] if b2 is not None else 0, _lib.ptr(rr), _lib.ptr(out), B, H, W, Cout,

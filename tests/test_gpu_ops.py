@@ -194,6 +194,56 @@ def test_conv3x3_winograd(G, case):
     assert C.rel_l2(got0, ref0) < TOL
 
 
+W2D_CASES = [
+    # B, H, W, C1, C2, Cout, has_b2, has_res, scale, silu
+    (8, 64, 64, 64, 0, 64, True, True, 0.70710678, True),        # 128 tiles x 1 channel block, two chunks
+    (2, 128, 128, 128, 0, 128, True, True, 0.70710678, True),    # 128 tiles x 2 channel blocks, 4 chunks, tiles per block 1
+    (8, 128, 128, 128, 0, 128, False, True, 1.0, True),          # 1024 block-tiles: two tiles per block (pipeline across tiles)
+    (2, 256, 128, 64, 32, 128, True, False, 1.0, True),          # concat 64 + 32: odd chunk count (3), tiles per block 1
+    (1, 256, 256, 128, 128, 256, True, True, 1.0, False),        # concat, 8 chunks, GroupNorm without SiLU, Cout 256
+    (4, 64, 192, 32, 0, 64, False, False, 1.0, True),            # one chunk per tile, W = 12 tiles (row-major walk)
+]
+
+
+@pytest.mark.parametrize("case", W2D_CASES)
+def test_conv3x3_winograd_2d(G, case):
+    """F(4,3) x F(2,3) two-dimensional Winograd kernel (with and without the fused GroupNorm + SiLU input stage) against
+    the plain fp64 direct convolution, next to the 1-D F(4,3) kernel's error on the same input."""
+    B, H, W, C1, C2, Cout, has_b2, has_res, scale, silu = case
+    Cc = C1 + C2
+    x1 = rnd(41, (B, C1, H, W)) * 1.5 + 0.3
+    x2 = rnd(42, (B, C2, H, W)) * 0.7 - 0.2 if C2 else None
+    g = 1.0 + rnd(43, (Cc,), 0.2)
+    be = rnd(44, (Cc,), 0.2)
+    w = rnd(45, (Cout, Cc, 3, 3), (1.0 / (Cc * 9)) ** 0.5)
+    bias = rnd(46, (Cout,), 0.1)
+    bias2 = rnd(47, (B, Cout + 4), 0.1) if has_b2 else None
+    res = rnd(48, (B, Cout, H, W)) if has_res else None
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    hn = F.group_norm(xin, min(Cc // 4, 32), g, be, eps=1e-6)
+    if silu:
+        hn = F.silu(hn)
+
+    def finish(t):
+        if has_b2:
+            t = t + bias2[:, :Cout, None, None]
+        if has_res:
+            t = t + res
+        return t * scale
+
+    ref = finish(F.conv2d(hn.double(), w.double(), bias.double(), padding=1).float())
+    got = G.conv3x3_f43(x1, w, g, be, bias, x2, bias2, res, scale, silu, form="w2d")
+    err = C.rel_l2(got, ref)
+    err1 = C.rel_l2(G.conv3x3_f43(x1, w, g, be, bias, x2, bias2, res, scale, silu), ref)
+    print(f"winograd 2-D rel-L2 {err:.2e}   1-D F(4,3) kernel {err1:.2e}")
+    assert err < TOL
+    again = G.conv3x3_f43(x1, w, g, be, bias, x2, bias2, res, scale, silu, form="w2d")
+    assert torch.equal(got, again), "two runs differ"
+    ref0 = finish(F.conv2d(xin.double(), w.double(), bias.double(), padding=1).float())
+    got0 = G.conv3x3_f43(x1, w, None, None, bias, x2, bias2, res, scale, form="w2d")
+    assert C.rel_l2(got0, ref0) < TOL
+
+
 def test_conv3x3_winograd_rejects_uncovered_shapes(G):
     """The Winograd entry point refuses shapes its tiling does not cover (status SHAPE + message) instead of
     silently running another kernel: small image, Cout not a multiple of 64, H not a multiple of 8."""
