@@ -566,8 +566,12 @@ def main():
                                    "own passes, 2*FETCH_SIZE + WRITE_SIZE)")
             form = None
             if args.precision == "fp32" and not os.environ.get("FLOWSE_NO_WINOGRAD"):
-                form = "F(4,3)"
-            kname = ("flowse::conv3x3_f43_kernel<2, false, 2>" +
+                form = "F(4,3)" if os.environ.get("FLOWSE_W2D", "1")[:1] == "0" else "F(4,3)xF(2,3)"
+            kname = ("flowse::conv3x3_w2d_kernel<2> (fp32 two-dimensional Winograd F(4,3) x F(2,3) implicit-GEMM 3x3 conv, 16x16 "
+                     "pixel x 64 channel block of 8 waves, LDS halo, fused GroupNorm+SiLU input, weights streamed from L2 in MFMA "
+                     "fragment order) on launches of >= 512 such blocks, flowse::conv3x3_f43_kernel<2, false, *> (1-D F(4,3)) on "
+                     "the smaller ones" if form == "F(4,3)xF(2,3)" else
+                     "flowse::conv3x3_f43_kernel<2, false, 2>" +
                      f" (fp32 {form}-Winograd implicit-GEMM 3x3 conv, 8x16 pixel x 128 channel block, LDS halo, fused "
                      "GroupNorm+SiLU input, weights streamed from L2 in MFMA fragment order)" if form else
                      "flowse::conv3x3_halo_kernel<2,2,2,2,2> (fp32 implicit-GEMM 3x3 conv, 128x128 tile, LDS halo, "
@@ -575,16 +579,19 @@ def main():
                      "flowse::conv3x3_halo_bf16_kernel (fp32 storage, split-bf16 x3 operands, LDS halo)" if args.precision == "bf16x3" else
                      "flowse::conv3x3_pc16_kernel (+ conv3x3_halo_bf16_kernel on small launches): persistent producer/consumer "
                      "LDS-halo 3x3 conv, 16-bit MFMA operands, fused GroupNorm+SiLU input")
-            issue = {"F(4,3)": 0.5, None: 3.0 if args.precision == "bf16x3" else 1.0}[form]
-            issued = ach * issue
+            # FLOPs the matrix cores execute for the bracketed launches, counted per launch by the library (1/3 of the direct
+            # convolution's for the 2-D Winograd kernel, 1/2 for 1-D F(4,3), 3x for the split-bf16 mode)
+            issued = dom["issued"] / (dom["ms"] * 1e-3) / 1e12
+            issue = issued / ach
             peak = PEAK_FP32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_16BIT_MATRIX_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": issued, "peak": peak, "unit": "TFLOP/s",
                                "frac": issued / peak,
                                "achieved_definition": "FLOPs the matrix cores execute per launch / launch time"
-                                                      + (f": {form} Winograd issues {issue:.3g} of the algorithmic "
-                                                         "direct-convolution FLOPs (SURVEY 8d), which are reported as "
-                                                         "achieved_algorithmic" if form else
+                                                      + (f": the {form} Winograd kernels issue {issue:.3g} of the algorithmic "
+                                                         "direct-convolution FLOPs of these launches (1/3 per 2-D launch, 1/2 per "
+                                                         "1-D launch; SURVEY 8d), which are reported as achieved_algorithmic"
+                                                         if form else
                                                          " (= the algorithmic direct-convolution FLOPs of SURVEY 8d)"),
                                "achieved_algorithmic": ach,
                                "whole_path_algorithmic_TFLOPs": value * nfe_per_step * FLOP_PER_FRAME_NFE / world / 1e12,

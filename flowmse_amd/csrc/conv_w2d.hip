@@ -275,24 +275,31 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
         return second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, soff, 0)
                       : __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, soff, 0);
     };
-    auto gparams = [&](int chunk) {
+    // Zero padding applies AFTER the activation.  Rows outside the image: the thread's scale and shift are zeroed for the
+    // whole chunk (its requests return 0, (0 - mean) * 0 + 0 = 0 and SiLU(0) = 0) -- `hin` bit 1 = columns 3..5 of the
+    // halo, always inside horizontally, i.e. "this thread's ROW is inside".  Columns outside the image only occur in the
+    // first and the last round (halo columns 0 and 17): only those two quads carry a select.
+    auto gparams = [&](int chunk, unsigned hin) {
         if (GN) {
             const int cg = chunk * KC + col4 * 4;
+            const float rowf = (hin >> 1) & 1u ? 1.f : 0.f;
             g_mu = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg);
             g_sc = *reinterpret_cast<const float4*>(a.gn.scale + (int64_t)b * Cin + cg);
             g_be = *reinterpret_cast<const float4*>(a.gn.beta + cg);
+            g_sc.x *= rowf; g_sc.y *= rowf; g_sc.z *= rowf; g_sc.w *= rowf;
+            g_be.x *= rowf; g_be.y *= rowf; g_be.z *= rowf; g_be.w *= rowf;
         }
     };
     auto gloadH = [&](const W2Tile& t, int chunk, int h) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) rh[q] = hload(t, chunk, 3 * h + q);
         if (h == 0) {
-            gparams(chunk);
+            gparams(chunk, t.hin);
             st_hin = t.hin;
         }
     };
     auto xform1 = [&](int Q) {
-        if (GN) rh[Q % 3] = gn_quad<GN>(rh[Q % 3], g_mu, g_sc, g_be, (st_hin >> Q) & 1u);
+        if (GN) rh[Q % 3] = gn_quad<GN>(rh[Q % 3], g_mu, g_sc, g_be, (Q == 0 || Q == 5) ? ((st_hin >> Q) & 1u) != 0 : true);
     };
     auto lstoreH = [&](int buf, int h) {
         float* Hb = Hs + buf * W2_HBUF + s_lds + 9 * h * LDS_ROW;
@@ -320,6 +327,9 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
     const int nchunks = Cin / KC;
     const unsigned wslice = (unsigned)((n0 >> 5) * 4 + hq) * (unsigned)nchunks;     // in 24 KB units; tile j adds 4 nchunks
     const unsigned wvo = (unsigned)lane * 16u + (unsigned)CH * 3u * 4096u;
+    unsigned wvoc[3] = {wvo, wvo + 4096u, wvo + 8192u};
+    asm volatile("" : "+v"(wvoc[0]), "+v"(wvoc[1]), "+v"(wvoc[2]));     // three registers, not an add per request
+    const unsigned wj = 4u * (unsigned)nchunks * 24576u;                 // channel tile 1
 
     f32x16 acc[3][2];                                    // this wave's three vertical components x two channel tiles
 
@@ -327,10 +337,10 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
         u32x4 t[H_LOADS];
 #pragma unroll
         for (int q = 0; q < H_LOADS; ++q) t[q] = hload(cur, 0, q);
-        gparams(0);
+        gparams(0, cur.hin);
 #pragma unroll
         for (int q = 0; q < H_LOADS; ++q) {
-            if (GN) t[q] = gn_quad<GN>(t[q], g_mu, g_sc, g_be, (cur.hin >> q) & 1u);
+            if (GN) t[q] = gn_quad<GN>(t[q], g_mu, g_sc, g_be, (q == 0 || q == 5) ? ((cur.hin >> q) & 1u) != 0 : true);
             if (s_on) *reinterpret_cast<u32x4*>(Hs + s_lds + 3 * q * LDS_ROW) = t[q];
         }
     }
@@ -339,10 +349,11 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
 #define W2_FENCE __builtin_amdgcn_sched_barrier(0);
 #define W2_RD(BASE0, BASE1, R, J) \
     (*reinterpret_cast<const float4*>(Hcur + ((CH + (R)) >= 4 ? (BASE1) : (BASE0)) + (R) * W2_HROW + (J) * 8))
-#define W2_BLOAD(C, JT, J, CHK, BF)                                                                                  \
+    // weight fragment (component C, channel tile JT, k-block J) of the chunk whose per-tile scalar offsets are WB[0..1]:
+    // voffset = one register per component, k-block in the 12-bit immediate, everything else in the scalar offset
+#define W2_BLOAD(C, JT, J, WB, BF)                                                                                   \
     {                                                                                                                \
-        const unsigned so = (wslice + (unsigned)(4 * (JT)) * (unsigned)nchunks + (unsigned)(CHK)) * 24576u;          \
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, wvo + ((C) * 4 + (J)) * 1024, so, 0);           \
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, wvoc[C] + (J) * 1024, WB[JT], 0);               \
         BF[C][JT] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z),                    \
                                 __uint_as_float(t.w));                                                               \
     }
@@ -397,21 +408,22 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
         W2_FENCE                                                                                                     \
     }
     // k-step y with the next k-block's six weight requests (and the last combination) in its gaps
-#define W2_GY(V, BF, DN, TN, BFN, NJ, NCHK)                                                                          \
+#define W2_GY(V, BF, DN, TN, BFN, NJ, WB)                                                                          \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                    \
         W2_M1(V, BF, y, c, j)                                                                                        \
         W2_FENCE                                                                                                     \
-        W2_BLOAD(c, j, NJ, NCHK, BFN)                                                                                \
+        W2_BLOAD(c, j, NJ, WB, BFN)                                                                                  \
         if (c * 2 + j == 0) W2_COMB(DN, TN, 4, 1)                                                                    \
         W2_FENCE                                                                                                     \
     }
 
     float4 dA[5], dB[5], tN[3], bA[3][2], bB[3][2];
     auto first_weights = [&]() {
+        const unsigned wb[2] = {wslice * 24576u, wslice * 24576u + wj};
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) W2_BLOAD(c, j, 0, 0, bA)
+            for (int j = 0; j < 2; ++j) W2_BLOAD(c, j, 0, wb, bA)
     };
     first_weights();
     // ---- tiles of this block; the staging pipeline runs ACROSS tile boundaries (the halo of the next tile's first chunk
@@ -431,8 +443,12 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
             const bool wrap = chunk + 1 >= nchunks;      // the tile's last chunk stages for the block's next tile
             const int cnext = wrap ? (more ? 0 : nchunks - 1) : chunk + 1, nbuf = (chunk + 1) & 1;
             const W2Tile stile = (wrap && more) ? make_tile(mg * tpb + ti + 1) : cur;
+            const unsigned wb[2] = {(wslice + (unsigned)chunk) * 24576u, (wslice + (unsigned)chunk) * 24576u + wj};
+            // first weights of the next chunk; at a tile's last chunk: chunk 0 again (the next tile's, requested anew after
+            // the output stage -- 24 registers that would otherwise have to survive it; here only to keep the loop branch-free)
+            const unsigned wbn0 = wrap ? wslice * 24576u : wb[0] + 24576u;
+            const unsigned wbn[2] = {wbn0, wbn0 + wj};
             // k-block 0 of this chunk: nothing to hide it behind (the buffer became valid at the barrier)
-            gloadH(stile, cnext, 0);
 #pragma unroll
             for (int r = 0; r < 5; ++r) dA[r] = W2_RD(aA0, aA1, r, 0);
 #pragma unroll
@@ -446,13 +462,16 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
             W2_WXA(dA) W2_WXB(dA)
             W2_FENCE
             // phase 0
-            W2_GX(dA, bA, dB, tN, 1) W2_GY(dA, bA, dB, tN, bB, 1, chunk)
+            W2_GX(dA, bA, dB, tN, 1)
+            gloadH(stile, cnext, 0);                     // (its scalar address work rides behind the MFMAs)
+            W2_FENCE
+            W2_GY(dA, bA, dB, tN, bB, 1, wb)
             W2_WXA(dB) W2_FENCE W2_MMA6(dA, bA, z) W2_FENCE W2_WXB(dB) W2_FENCE W2_MMA6(dA, bA, w) W2_FENCE
             // phase 1: the first half of the next halo is normalised here
             W2_GX(dB, bB, dA, tN, 2)
             xform1(0);
             W2_FENCE
-            W2_GY(dB, bB, dA, tN, bA, 2, chunk)
+            W2_GY(dB, bB, dA, tN, bA, 2, wb)
             xform1(1);
             W2_FENCE
             W2_WXA(dA) W2_FENCE W2_MMA6(dB, bB, z) W2_FENCE
@@ -462,7 +481,7 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
             gloadH(stile, cnext, 1);
             W2_FENCE
             // phase 2
-            W2_GX(dA, bA, dB, tN, 3) W2_GY(dA, bA, dB, tN, bB, 3, chunk)
+            W2_GX(dA, bA, dB, tN, 3) W2_GY(dA, bA, dB, tN, bB, 3, wb)
             W2_WXA(dB) W2_FENCE W2_MMA6(dA, bA, z) W2_FENCE W2_WXB(dB) W2_FENCE W2_MMA6(dA, bA, w) W2_FENCE
             // phase 3: no next k-block in this chunk; first weights of the next chunk (a next TILE's: after the output stage)
             W2_MMA6(dB, bB, x) W2_FENCE
@@ -471,7 +490,7 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
             _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int j = 0; j < 2; ++j) {
                 W2_M1(dB, bB, y, c, j)
                 W2_FENCE
-                if (!wrap) W2_BLOAD(c, j, 0, cnext, bA)
+                W2_BLOAD(c, j, 0, wbn, bA)
                 W2_FENCE
             }
             xform1(4);

@@ -4,7 +4,7 @@
 bias -- the ResnetBlock call.  The GroupNorm statistics launches of the op-level entry are outside the timed region
 (the timed calls run with gamma == NULL unless --gn; kernel-only timing: use rocprofv3 --kernel-trace --stats).
 
-    python tools/bench_wino.py [--gn] [--iters N]
+    python tools/bench_wino.py [--gn] [--iters N] [--only SHAPE_INDEX] [--form f43|w2d]
 """
 import os
 import sys
@@ -31,7 +31,7 @@ SHAPES = [  # B, H, W, C1, C2, Cout   (launches per NFE at [8,1,256,256])
 ]
 
 
-def run(shape, iters, gn):
+def run(shape, iters, gn, forms=("f43", "w2d")):
     B, H, W, C1, C2, Cout = shape
     C = C1 + C2
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -44,7 +44,7 @@ def run(shape, iters, gn):
     res = torch.randn(B, H, W, Cout, generator=g).cuda()
     st = _lib.current_stream()
     outs, line = {}, f"{str(shape):34s}"
-    for form in ("f43", "w2d"):
+    for form in forms:
         out = torch.empty(B, H, W, Cout, device="cuda")
         scratch = torch.empty(getattr(L, f"flowse_op_conv3x3_{form}_scratch_floats")(B, H, W, C, Cout), device="cuda")
         fn = getattr(L, f"flowse_op_conv3x3_{form}")
@@ -78,5 +78,8 @@ if __name__ == "__main__":
     it = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 10
     print("# per call incl. the weight transform" + (" and GroupNorm statistics launches" if "--gn" in sys.argv else "") +
           " (op-level entry); kernel-only times: rocprofv3 --kernel-trace --stats")
-    for s in SHAPES:
-        run(s, it, "--gn" in sys.argv)
+    only = int(sys.argv[sys.argv.index("--only") + 1]) if "--only" in sys.argv else None
+    forms = (sys.argv[sys.argv.index("--form") + 1],) if "--form" in sys.argv else ("f43", "w2d")
+    for k, s in enumerate(SHAPES):
+        if only is None or k == only:
+            run(s, it, "--gn" in sys.argv, forms)
