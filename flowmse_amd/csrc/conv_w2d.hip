@@ -76,6 +76,7 @@ __device__ __forceinline__ void w2d_out(f32x16 (&acc)[3][2], float* X, int b, in
         const int pp = i * 8 + pl;                       // pixel of the 4 x 16 strip, row-major
         roff[i] = ((pp >> 4) * W + (pp & 15)) * Cout;
     }
+    // residual quads are requested first: in flight during the whole exchange
     float4 rres[8];
     if (has_res) {
 #pragma unroll
@@ -133,6 +134,11 @@ __device__ __forceinline__ void w2d_out(f32x16 (&acc)[3][2], float* X, int b, in
     __syncthreads();
     if (CH == 1) give();
     __syncthreads();
+    // (bias quads: L2 hits, requested here -- under the second round's reads and sums -- not before the exchange, where
+    // eight more live registers spill)
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), bq2 = bq;
+    if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + ch0 + cq * 4);
+    if (a.bias2) bq2 = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)b * a.bias2_stride + ch0 + cq * 4);
     take(SB);
     // ---- transpose through this wave's own slice (nobody else reads it), finish, store, statistics
     float* T = Xd;                                       // [64 pixels][32 channels]
@@ -151,12 +157,7 @@ __device__ __forceinline__ void w2d_out(f32x16 (&acc)[3][2], float* X, int b, in
             T[(3 * 16 + col) * 32 + li] = o3;
         }
     __builtin_amdgcn_wave_barrier();
-    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + ch0 + cq * 4);
-    if (a.bias2) {
-        const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)b * a.bias2_stride + ch0 + cq * 4);
-        bq.x += t.x; bq.y += t.y; bq.z += t.z; bq.w += t.w;
-    }
+    bq.x += bq2.x; bq.y += bq2.y; bq.z += bq2.z; bq.w += bq2.w;
     const float scale = a.scale;
     float4 piv = make_float4(0.f, 0.f, 0.f, 0.f), s1 = piv, s2 = piv;
 #pragma unroll
@@ -224,6 +225,8 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
     const int s_hx = slot >= 36 ? 2 : slot >= 18 ? 1 : 0, s_hy = slot - 18 * s_hx;
     const unsigned s_pix = (unsigned)(s_hy * W + s_hx);  // pixel offset of round 0 inside the window
     const int s_lds = s_hy * W2_HROW + s_hx * LDS_ROW + 4 * (col4 ^ ((s_hy >> 2) & 1));
+    int s_st = s_lds + W2_HBUF;                          // staging store base: the buffer NOT being read
+    int dflip = W2_HBUF;                                 // read bases += dflip, store base -= dflip at every slot barrier
     // tiles of an image are walked in vertical strips of 4 tiles (64 pixels), top to bottom (as conv_f43.hip)
     const int bsmp = (mg * tpb) / tiles_img;
     const int b = bsmp;
@@ -256,7 +259,8 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
         t.woff = (unsigned)(t.y0 * W + t.x0);
         return t;
     };
-    W2Tile cur = make_tile(mg * tpb);
+    const W2Tile first = make_tile(mg * tpb);
+    int cur_y0 = first.y0, cur_x0 = first.x0;            // the tile being computed (the staged one runs ahead: stg)
     const __amdgpu_buffer_rsrc_t rsrcw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wino2), 0, a.Cout * 24 * Cin * 4, 0x00020000);
 
@@ -264,7 +268,7 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
     // write into the idle buffer): 12 staging registers live at any time
     u32x4 rh[3];
     float4 g_mu, g_sc, g_be;
-    unsigned st_hin = cur.hin;                           // halo mask of the tile being STAGED
+    unsigned st_hin = first.hin;                          // halo mask of the tile being STAGED
 
     auto hload = [&](const W2Tile& t, int chunk, int Q) -> u32x4 {
         const int c0 = chunk * KC;
@@ -301,8 +305,8 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
     auto xform1 = [&](int Q) {
         if (GN) rh[Q % 3] = gn_quad<GN>(rh[Q % 3], g_mu, g_sc, g_be, (Q == 0 || Q == 5) ? ((st_hin >> Q) & 1u) != 0 : true);
     };
-    auto lstoreH = [&](int buf, int h) {
-        float* Hb = Hs + buf * W2_HBUF + s_lds + 9 * h * LDS_ROW;
+    auto lstoreH = [&](int h) {
+        float* Hb = Hs + s_st + 9 * h * LDS_ROW;
         if (s_on) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(Hb + 3 * q * LDS_ROW) = rh[q];
@@ -321,8 +325,9 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
     // bit = (ur + ((CH + r) >> 2)) & 1 -- two address variants per column (rows without / with the carry)
     const int base = (4 * ur + CH) * W2_HROW + 2 * uc * LDS_ROW;
     const int k0 = 4 * (kh ^ (ur & 1)), k1 = 4 * (kh ^ (ur & 1) ^ 1);
-    const int aA0 = base + ca * LDS_ROW + k0, aA1 = base + ca * LDS_ROW + k1;
-    const int aB0 = base + cb * LDS_ROW + k0, aB1 = base + cb * LDS_ROW + k1;
+    int aA0 = base + ca * LDS_ROW + k0, aA1 = base + ca * LDS_ROW + k1;
+    int aB0 = base + cb * LDS_ROW + k0, aB1 = base + cb * LDS_ROW + k1;
+
     // weight fragments: 24 KB per (32-channel slice, h, chunk), [component 0..5][k-block][lane][4 floats]
     const int nchunks = Cin / KC;
     const unsigned wslice = (unsigned)((n0 >> 5) * 4 + hq) * (unsigned)nchunks;     // in 24 KB units; tile j adds 4 nchunks
@@ -336,19 +341,21 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
     {   // first chunk of the block's first tile: all quads at once (the accumulators are not live yet)
         u32x4 t[H_LOADS];
 #pragma unroll
-        for (int q = 0; q < H_LOADS; ++q) t[q] = hload(cur, 0, q);
-        gparams(0, cur.hin);
+        for (int q = 0; q < H_LOADS; ++q) t[q] = hload(first, 0, q);
+        gparams(0, first.hin);
 #pragma unroll
         for (int q = 0; q < H_LOADS; ++q) {
-            if (GN) t[q] = gn_quad<GN>(t[q], g_mu, g_sc, g_be, (q == 0 || q == 5) ? ((cur.hin >> q) & 1u) != 0 : true);
+            if (GN) t[q] = gn_quad<GN>(t[q], g_mu, g_sc, g_be, (q == 0 || q == 5) ? ((first.hin >> q) & 1u) != 0 : true);
             if (s_on) *reinterpret_cast<u32x4*>(Hs + s_lds + 3 * q * LDS_ROW) = t[q];
         }
     }
     __syncthreads();
 
 #define W2_FENCE __builtin_amdgcn_sched_barrier(0);
+    // (the four base registers INCLUDE the offset of the buffer being read and are flipped at the slot barrier: every
+    // LDS read is base register + immediate; buffer-specific copies of the bases were being spilled)
 #define W2_RD(BASE0, BASE1, R, J) \
-    (*reinterpret_cast<const float4*>(Hcur + ((CH + (R)) >= 4 ? (BASE1) : (BASE0)) + (R) * W2_HROW + (J) * 8))
+    (*reinterpret_cast<const float4*>(Hs + ((CH + (R)) >= 4 ? (BASE1) : (BASE0)) + (R) * W2_HROW + (J) * 8))
     // weight fragment (component C, channel tile JT, k-block J) of the chunk whose per-tile scalar offsets are WB[0..1]:
     // voffset = one register per component, k-block in the 12-bit immediate, everything else in the scalar offset
 #define W2_BLOAD(C, JT, J, WB, BF)                                                                                   \
@@ -364,150 +371,171 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
         W2_H2(D[R], 0) = __builtin_elementwise_fma(sg2, W2_H2(T[TR], 0), W2_H2(D[R], 0));                            \
         W2_H2(D[R], 1) = __builtin_elementwise_fma(sg2, W2_H2(T[TR], 1), W2_H2(D[R], 1));                            \
     }
-    // vertical input transform, in place (as conv_f43.hip): D[0..2] (CH 0) / D[4], D[1], D[2] (CH 1) become the operands
-#define W2_WXA(D)                                                                                                    \
+    // vertical input transform, in place (as conv_f43.hip), per float2 half h: D[0..2] (CH 0) / D[4], D[1], D[2] (CH 1)
+    // become the operands
+#define W2_WXA_H(D, h)                                                                                               \
     {                                                                                                                \
         const f32x2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f};                                                             \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                              \
-            const f32x2 r0 = W2_H2(D[0], h), r2 = W2_H2(D[2], h), r4 = W2_H2(D[4], h);                               \
-            const f32x2 v = __builtin_elementwise_fma(c4, r0, __builtin_elementwise_fma(cm5, r2, r4));               \
-            if (CH == 0) W2_H2(D[0], h) = v;                                                                         \
-            else W2_H2(D[4], h) = v;                                                                                 \
-        }                                                                                                            \
+        const f32x2 r0 = W2_H2(D[0], h), r2 = W2_H2(D[2], h), r4 = W2_H2(D[4], h);                                   \
+        const f32x2 v = __builtin_elementwise_fma(c4, r0, __builtin_elementwise_fma(cm5, r2, r4));                   \
+        if (CH == 0) W2_H2(D[0], h) = v;                                                                             \
+        else W2_H2(D[4], h) = v;                                                                                     \
     }
-#define W2_WXB(D)                                                                                                    \
+#define W2_WXB_H(D, h)                                                                                               \
     {                                                                                                                \
         const f32x2 c4 = {4.f, 4.f}, cm4 = {-4.f, -4.f}, c2 = {2.f, 2.f}, cm2 = {-2.f, -2.f};                        \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                              \
-            const f32x2 r0 = W2_H2(D[0], h), r1 = W2_H2(D[1], h), r2 = W2_H2(D[2], h), r3 = W2_H2(D[3], h),          \
-                        r4 = W2_H2(D[4], h);                                                                         \
-            if (CH == 0) {                                                                                           \
-                W2_H2(D[1], h) = __builtin_elementwise_fma(cm4, r1 + r2, r3 + r4);                                   \
-                W2_H2(D[2], h) = __builtin_elementwise_fma(c4, r1 - r2, r4 - r3);                                    \
-            } else {                                                                                                 \
-                W2_H2(D[1], h) = __builtin_elementwise_fma(c2, r2 - r0, r3 - r1);                                    \
-                W2_H2(D[2], h) = __builtin_elementwise_fma(cm2, r2 - r0, r3 - r1);                                   \
-            }                                                                                                        \
+        const f32x2 r0 = W2_H2(D[0], h), r1 = W2_H2(D[1], h), r2 = W2_H2(D[2], h), r3 = W2_H2(D[3], h),              \
+                    r4 = W2_H2(D[4], h);                                                                             \
+        if (CH == 0) {                                                                                               \
+            W2_H2(D[1], h) = __builtin_elementwise_fma(cm4, r1 + r2, r3 + r4);                                       \
+            W2_H2(D[2], h) = __builtin_elementwise_fma(c4, r1 - r2, r4 - r3);                                        \
+        } else {                                                                                                     \
+            W2_H2(D[1], h) = __builtin_elementwise_fma(c2, r2 - r0, r3 - r1);                                        \
+            W2_H2(D[2], h) = __builtin_elementwise_fma(cm2, r2 - r0, r3 - r1);                                       \
         }                                                                                                            \
     }
-#define W2_M1(V, BF, K, c, j)                                                                                        \
-    acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[((c) == 0 && CH == 1) ? 4 : (c)].K, BF[c][j].K, acc[c][j], 0, 0, 0);
-#define W2_MMA6(V, BF, K)                                                                                            \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int j = 0; j < 2; ++j) W2_M1(V, BF, K, c, j)
-    // k-step x with the next k-block's ten LDS reads riding in its gaps, one row (two columns) per MFMA, and the
-    // horizontal combination of a row two gaps after its reads (three rows of the second column live at a time)
-#define W2_GX(V, BF, DN, TN, NJ)                                                                                     \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                    \
-        W2_M1(V, BF, x, c, j)                                                                                        \
-        W2_FENCE                                                                                                     \
-        if (c * 2 + j < 5) {                                                                                         \
-            DN[c * 2 + j] = W2_RD(aA0, aA1, c * 2 + j, NJ);                                                          \
-            TN[(c * 2 + j) % 3] = W2_RD(aB0, aB1, c * 2 + j, NJ);                                                    \
-        }                                                                                                            \
-        if (c * 2 + j >= 2) W2_COMB(DN, TN, c * 2 + j - 2, (c * 2 + j - 2) % 3)                                      \
-        W2_FENCE                                                                                                     \
-    }
-    // k-step y with the next k-block's six weight requests (and the last combination) in its gaps
-#define W2_GY(V, BF, DN, TN, BFN, NJ, WB)                                                                          \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                    \
-        W2_M1(V, BF, y, c, j)                                                                                        \
-        W2_FENCE                                                                                                     \
-        W2_BLOAD(c, j, NJ, WB, BFN)                                                                                  \
-        if (c * 2 + j == 0) W2_COMB(DN, TN, 4, 1)                                                                    \
-        W2_FENCE                                                                                                     \
-    }
+#define W2_WXA(D) { W2_WXA_H(D, 0) W2_WXA_H(D, 1) }
+#define W2_WXB(D) { W2_WXB_H(D, 0) W2_WXB_H(D, 1) }
+    // One k-block (8 channels per lane half: four MFMA k-steps) = 24 MFMAs in COMPONENT-MAJOR order: the eight MFMAs of
+    // component c (k-steps x..w, the two channel tiles alternating -- never two MFMAs in a row on one accumulator) run
+    // before component c + 1 starts.  The operands of a component are therefore dead after its eighth MFMA and the NEXT
+    // k-block's weight fragments are requested straight into the same registers, a full k-block (16 MFMAs) before their
+    // use: ONE set of 24 weight registers instead of two -- the two-set form sat at the 256-register cap and reloaded
+    // spilled addresses through the in-order vector-memory queue.  Every other instruction rides in an MFMA gap: the ten
+    // LDS reads of the next k-block and their horizontal combinations behind component 0, the vertical transform behind
+    // component 1, one staged GroupNorm quad (SX) behind component 2.
+#define W2_MF(V, c, K, j)                                                                                            \
+    acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[((c) == 0 && CH == 1) ? 4 : (c)].K, bF[c][j].K, acc[c][j], 0, 0, 0); \
+    W2_FENCE
+#define W2_PHASE(V, DN, NJ, WB, SX)                                                                                  \
+    W2_MF(V, 0, x, 0) DN[0] = W2_RD(aA0, aA1, 0, NJ); tN[0] = W2_RD(aB0, aB1, 0, NJ); W2_FENCE                       \
+    W2_MF(V, 0, x, 1) DN[1] = W2_RD(aA0, aA1, 1, NJ); tN[1] = W2_RD(aB0, aB1, 1, NJ); W2_FENCE                       \
+    W2_MF(V, 0, y, 0) DN[2] = W2_RD(aA0, aA1, 2, NJ); tN[2] = W2_RD(aB0, aB1, 2, NJ); W2_COMB(DN, tN, 0, 0) W2_FENCE \
+    W2_MF(V, 0, y, 1) DN[3] = W2_RD(aA0, aA1, 3, NJ); tN[0] = W2_RD(aB0, aB1, 3, NJ); W2_COMB(DN, tN, 1, 1) W2_FENCE \
+    W2_MF(V, 0, z, 0) DN[4] = W2_RD(aA0, aA1, 4, NJ); tN[1] = W2_RD(aB0, aB1, 4, NJ); W2_COMB(DN, tN, 2, 2) W2_FENCE \
+    W2_MF(V, 0, z, 1) W2_COMB(DN, tN, 3, 0) W2_FENCE                                                                 \
+    W2_MF(V, 0, w, 0) W2_COMB(DN, tN, 4, 1) W2_FENCE                                                                 \
+    W2_MF(V, 0, w, 1) W2_BLOAD(0, 0, NJ, WB, bF) W2_FENCE                                                            \
+    W2_MF(V, 1, x, 0) W2_BLOAD(0, 1, NJ, WB, bF) W2_FENCE                                                            \
+    W2_MF(V, 1, x, 1) W2_WXA_H(DN, 0) W2_FENCE                                                                       \
+    W2_MF(V, 1, y, 0) W2_WXA_H(DN, 1) W2_FENCE                                                                       \
+    W2_MF(V, 1, y, 1) W2_WXB_H(DN, 0) W2_FENCE                                                                       \
+    W2_MF(V, 1, z, 0) W2_WXB_H(DN, 1) W2_FENCE                                                                       \
+    W2_MF(V, 1, z, 1)                                                                                                \
+    W2_MF(V, 1, w, 0)                                                                                                \
+    W2_MF(V, 1, w, 1) W2_BLOAD(1, 0, NJ, WB, bF) W2_FENCE                                                            \
+    W2_MF(V, 2, x, 0) W2_BLOAD(1, 1, NJ, WB, bF) W2_FENCE                                                            \
+    W2_MF(V, 2, x, 1) SX W2_FENCE                                                                                    \
+    W2_MF(V, 2, y, 0)                                                                                                \
+    W2_MF(V, 2, y, 1)                                                                                                \
+    W2_MF(V, 2, z, 0)                                                                                                \
+    W2_MF(V, 2, z, 1)                                                                                                \
+    W2_MF(V, 2, w, 0)                                                                                                \
+    W2_MF(V, 2, w, 1) W2_BLOAD(2, 0, NJ, WB, bF) W2_BLOAD(2, 1, NJ, WB, bF) W2_FENCE
 
-    float4 dA[5], dB[5], tN[3], bA[3][2], bB[3][2];
-    auto first_weights = [&]() {
+    float4 dA[5], dB[5], tN[3], bF[3][2];
+    // operands of a tile's first k-block: requests (LDS rows + weights) and, later, combination + transform.  The block's
+    // first tile issues both back to back; at a tile boundary the requests go out inside the output stage (before its
+    // stores) and the rest follows it.
+    auto start_issue = [&]() {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) dA[r] = W2_RD(aA0, aA1, r, 0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) tN[r] = W2_RD(aB0, aB1, r, 0);
         const unsigned wb[2] = {wslice * 24576u, wslice * 24576u + wj};
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) W2_BLOAD(c, j, 0, wb, bA)
+            for (int j = 0; j < 2; ++j) W2_BLOAD(c, j, 0, wb, bF)
     };
-    first_weights();
-    // ---- tiles of this block; the staging pipeline runs ACROSS tile boundaries (the halo of the next tile's first chunk
-    // is staged during this tile's last chunk), so only the block's first tile pays a prologue.  tpb > 1 needs an even
-    // number of chunks (every tile then starts in buffer 0; the output stage's exchange region lies behind it).
-    for (int ti = 0; ti < tpb; ++ti) {
-        const bool more = ti + 1 < tpb;
-        const int y0 = cur.y0, x0 = cur.x0;
+    auto start_finish = [&]() {
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) W2_COMB(dA, tN, r, r)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int r = 3; r < 5; ++r) tN[r - 3] = W2_RD(aB0, aB1, r, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const float* Hcur = Hs + (chunk & 1) * W2_HBUF;
-            const bool wrap = chunk + 1 >= nchunks;      // the tile's last chunk stages for the block's next tile
-            const int cnext = wrap ? (more ? 0 : nchunks - 1) : chunk + 1, nbuf = (chunk + 1) & 1;
-            const W2Tile stile = (wrap && more) ? make_tile(mg * tpb + ti + 1) : cur;
-            const unsigned wb[2] = {(wslice + (unsigned)chunk) * 24576u, (wslice + (unsigned)chunk) * 24576u + wj};
-            // first weights of the next chunk; at a tile's last chunk: chunk 0 again (the next tile's, requested anew after
-            // the output stage -- 24 registers that would otherwise have to survive it; here only to keep the loop branch-free)
-            const unsigned wbn0 = wrap ? wslice * 24576u : wb[0] + 24576u;
-            const unsigned wbn[2] = {wbn0, wbn0 + wj};
-            // k-block 0 of this chunk: nothing to hide it behind (the buffer became valid at the barrier)
-#pragma unroll
-            for (int r = 0; r < 5; ++r) dA[r] = W2_RD(aA0, aA1, r, 0);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) tN[r] = W2_RD(aB0, aB1, r, 0);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) W2_COMB(dA, tN, r, r)
-#pragma unroll
-            for (int r = 3; r < 5; ++r) tN[r - 3] = W2_RD(aB0, aB1, r, 0);
-#pragma unroll
-            for (int r = 3; r < 5; ++r) W2_COMB(dA, tN, r, r - 3)
-            W2_WXA(dA) W2_WXB(dA)
-            W2_FENCE
-            // phase 0
-            W2_GX(dA, bA, dB, tN, 1)
-            gloadH(stile, cnext, 0);                     // (its scalar address work rides behind the MFMAs)
-            W2_FENCE
-            W2_GY(dA, bA, dB, tN, bB, 1, wb)
-            W2_WXA(dB) W2_FENCE W2_MMA6(dA, bA, z) W2_FENCE W2_WXB(dB) W2_FENCE W2_MMA6(dA, bA, w) W2_FENCE
-            // phase 1: the first half of the next halo is normalised here
-            W2_GX(dB, bB, dA, tN, 2)
-            xform1(0);
-            W2_FENCE
-            W2_GY(dB, bB, dA, tN, bA, 2, wb)
-            xform1(1);
-            W2_FENCE
-            W2_WXA(dA) W2_FENCE W2_MMA6(dB, bB, z) W2_FENCE
-            xform1(2);
-            W2_WXB(dA) W2_FENCE W2_MMA6(dB, bB, w) W2_FENCE
-            lstoreH(nbuf, 0);
-            gloadH(stile, cnext, 1);
-            W2_FENCE
-            // phase 2
-            W2_GX(dA, bA, dB, tN, 3) W2_GY(dA, bA, dB, tN, bB, 3, wb)
-            W2_WXA(dB) W2_FENCE W2_MMA6(dA, bA, z) W2_FENCE W2_WXB(dB) W2_FENCE W2_MMA6(dA, bA, w) W2_FENCE
-            // phase 3: no next k-block in this chunk; first weights of the next chunk (a next TILE's: after the output stage)
-            W2_MMA6(dB, bB, x) W2_FENCE
-            xform1(3);
-            W2_FENCE
-            _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int j = 0; j < 2; ++j) {
-                W2_M1(dB, bB, y, c, j)
-                W2_FENCE
-                W2_BLOAD(c, j, 0, wbn, bA)
-                W2_FENCE
-            }
-            xform1(4);
-            W2_FENCE
-            W2_MMA6(dB, bB, z) W2_FENCE
-            xform1(5);
-            W2_FENCE
-            W2_MMA6(dB, bB, w) W2_FENCE
-            lstoreH(nbuf, 1);
-            __syncthreads();                             // next chunk's halo is complete; everyone has left this chunk's
+        for (int r = 3; r < 5; ++r) W2_COMB(dA, tN, r, r - 3)
+        W2_WXA(dA) W2_WXB(dA)
+    };
+    // ---- The block's work is a stream of SLOTS (tile ti, chunk): slot s lives in halo buffer s & 1.  While slot s is
+    // computed, slot s + 1 is staged (first half requested during slot s - 1's last phase, normalised and stored in
+    // phase 0; second half requested in phase 0, stored in phase 2) and ONE barrier sits at the end of phase 2: from there
+    // on buffer s & 1 is not read any more (phase 3 runs on operands read in phase 2) and buffer (s + 1) & 1 is complete,
+    // so phase 3 already reads and transforms slot s + 1's first operands behind its own MFMAs -- no wave ever starts a
+    // chunk with an empty matrix pipe.  The stream runs across tile boundaries; only the output stage interrupts it
+    // (its exchange region lies behind buffer 0 = the next tile's first chunk: tpb > 1 needs an even chunk count).
+    const int nslots = tpb * nchunks;
+    int sg_t = 0, sg_c = 0;                              // the slot being staged (tile within the block, chunk)
+    W2Tile stg = first;
+    auto stage_advance = [&]() {
+        if (++sg_c == nchunks) {
+            sg_c = 0;
+            ++sg_t;
+            if (sg_t < tpb) stg = make_tile(mg * tpb + sg_t);
         }
-        // the exchange region sits BEHIND halo buffer 0, which already holds the next tile's first chunk (tpb > 1)
-        w2d_out<CH>(acc, smem + W2_HBUF, b, y0, x0, n0);
-        if (more) {
-            first_weights();
+        if (sg_t >= tpb) {                               // past the block's last slot: a harmless repeat of its last chunk
+            sg_t = tpb;
+            sg_c = nchunks - 1;
+        }
+    };
+    stage_advance();                                     // slot 1
+    gloadH(stg, sg_c, 0);
+    start_issue();
+    start_finish();
+    int ti = 0, chunk = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+    for (int slot = 0; slot < nslots; ++slot) {
+        const bool last = chunk + 1 == nchunks;          // the tile's last chunk
+        const unsigned wb[2] = {(wslice + (unsigned)chunk) * 24576u, (wslice + (unsigned)chunk) * 24576u + wj};
+        const unsigned wbn0 = last ? wslice * 24576u : wb[0] + 24576u;       // slot + 1's chunk
+        const unsigned wbn[2] = {wbn0, wbn0 + wj};
+        // phase 0: the first half of slot + 1's halo is normalised (one quad per phase would leave the stores too late:
+        // two ride here, the third opens phase 1) and stored, its second half requested
+        W2_PHASE(dA, dB, 1, wb, { xform1(0); xform1(1); })
+        // phase 1
+        W2_PHASE(dB, dA, 2, wb, { xform1(2); lstoreH(0); gloadH(stg, sg_c, 1); })
+        // phase 2: the second half, then THE barrier of the slot
+        W2_PHASE(dA, dB, 3, wb, { xform1(3); xform1(4); })
+        xform1(5);
+        lstoreH(1);
+        __syncthreads();                                 // slot + 1's halo is complete; nobody reads this slot's any more
+        aA0 += dflip; aA1 += dflip; aB0 += dflip; aB1 += dflip;
+        s_st -= dflip;
+        dflip = -dflip;
+        asm volatile("" : "+v"(aA0), "+v"(aA1), "+v"(aB0), "+v"(aB1), "+v"(s_st));   // (five registers, not ten)
+        // phase 3: slot + 1's k-block 0 from the other buffer; slot + 2's first half is requested
+        stage_advance();
+        W2_PHASE(dB, dA, 0, wbn, { gloadH(stg, sg_c, 0); })
+        if (last) {
+            const bool more = ti + 1 < tpb;
+            w2d_out<CH>(acc, smem + W2_HBUF, b, cur_y0, cur_x0, n0);
+            if (!more) return;
             __syncthreads();                             // buffer 1 (under the exchange region) is written again in the next tile
-            cur = make_tile(mg * tpb + ti + 1);
+            // (the operands phase 3 fetched for the next tile were not kept across the output stage: 36 registers.  Requesting
+            // them inside the stage, ahead of its stores, and moving this barrier into the next tile's first phase both
+            // measured equal: profiles/r05_w2d_probes.md)
+            start_issue();
+            start_finish();
+            {
+                const W2Tile nx = make_tile(mg * tpb + ti + 1);
+                cur_y0 = nx.y0;
+                cur_x0 = nx.x0;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+            ++ti;
+            chunk = 0;
+        } else {
+            ++chunk;
         }
     }
 #undef W2_FENCE
@@ -517,10 +545,10 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
 #undef W2_COMB
 #undef W2_WXA
 #undef W2_WXB
-#undef W2_M1
-#undef W2_MMA6
-#undef W2_GX
-#undef W2_GY
+#undef W2_WXA_H
+#undef W2_WXB_H
+#undef W2_MF
+#undef W2_PHASE
 }
 
 template <int GN>
