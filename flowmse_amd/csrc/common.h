@@ -267,6 +267,11 @@ struct ConvArgs {
     // when set and the shape qualifies (conv_supports_w2d) the fp32 3x3 runs conv3x3_w2d_kernel -- its fused statistics
     // come in blocks of 64 pixels (4 x 16 strips: stats_nblk = H W / 64, set by the plan, Builder::conv)
     const float* wino2 = nullptr;
+    // optional copy of `w` in MFMA fragment order (launch_smallm_weights): when set and the shape qualifies
+    // (conv_smallm_ok) the fp32 conv runs conv_smallm_kernel -- K split inside the block, no slab, no second launch; its
+    // fused statistics come in blocks of min(32, H W) pixels (conv_smallm_stats_blocks)
+    const float* wsm = nullptr;
+    const float* wsm16 = nullptr;       // ... and in the 16 x 16-tile fragment order (<= 512 pixels: conv_smallm16_kernel)
     // activation storage types (DT_*).  16-bit inputs are taken by the 16-bit matrix-core kernels (halo 3x3 with
     // Cout % 128 == 0, flat 1x1 / small 3x3: `wq` = the [Cout][taps][Cin] weights in the matching 16-bit type, terms = 1)
     // and by the 4-channel heads; 16-bit outputs by those plus the 4-channel input convs, the fp32 flat kernel
@@ -295,6 +300,12 @@ inline int64_t conv_w2d_numel(int Cout, int Cin) { return (int64_t)Cout * 24 * C
 // ConvArgs::wino2 is set); conv_supports_w2d: ... and the policy wants it (enough blocks to fill the chip): the plan's test
 bool conv_w2d_shape_ok(int B, int H, int W, int C1, int C2, int Cout, int taps);
 bool conv_supports_w2d(int B, int H, int W, int C1, int C2, int Cout, int taps);
+// small-M kernel (conv_smallm.hip): shapes it takes (<= 1024 pixels in the batch, channel counts multiples of 32; honours
+// FLOWSE_NO_SMALLM=1), its weight copy and statistics geometry
+bool conv_smallm_ok(int B, int H, int W, int C1, int C2, int Cout, int taps);
+int launch_smallm_weights(const float* w_packed, int Cout, int taps, int Cin, float* out, hipStream_t s, bool tile16 = false);
+bool conv_smallm_tile16(int B, int H, int W);
+int conv_smallm_stats_blocks(int B, int H, int W);
 bool conv_w2d_enabled();                   // FLOWSE_W2D (read once): the model handle keeps the 2-D weights and uses the kernel
 bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // whole-K F(4,3) launches of this shape use 128-channel blocks (conv3x3_f43_kernel<GN, false, 2>)

@@ -8,6 +8,7 @@
 //   conv_w2d.hip      fp32 F(4,3) x F(2,3) two-dimensional Winograd 3x3 (large images, whole K)
 //   conv_halo.hip     direct fp32 LDS-halo 3x3, 4-channel heads / input layers
 //   conv_flat.hip     flat fp32 kernels: 1x1, small 3x3, split-K slices
+//   conv_smallm.hip   fp32 convs on <= 2048 pixels: K split inside the block (no slab, no reduction launch)
 //   conv_reduce.hip   second pass of split-K launches (+ fused GroupNorm statistics / GroupNorm)
 //   conv16.hip        16-bit operand / storage modes
 // Replaces (reference): ddpm_conv3x3 / ddpm_conv1x1 (flowmse/backbones/ncsnpp_utils/layers.py:100-124), NIN (:546-555).
@@ -25,6 +26,7 @@ int conv_splitk_stats_group(int HW) { return sk_pixels_per_block(HW); }
 int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps) {
     const int HW = H * W;
     if (Cout & 3) return 0;
+    if (conv_smallm_ok(B, H, W, Cin, 0, Cout, taps)) return conv_smallm_stats_blocks(B, H, W);
     if (conv_ksplit(B, H, W, Cin, Cout, taps) != 1) {      // statistics come from the split-K reduction
         const int PB = sk_pixels_per_block(HW);
         return ((HW % PB) == 0 && Cout / 4 <= 256) ? HW / PB : 0;
@@ -41,6 +43,17 @@ static const bool g_no_wino_policy = g_no_wino || g_no_halo || g_force_generic;
 // FLOWSE_W2D=0 keeps the 1-D F(4,3) kernel everywhere (A-B hook); default: the 2-D kernel where conv_supports_w2d says so
 static const bool g_w2d = !(getenv("FLOWSE_W2D") && getenv("FLOWSE_W2D")[0] == '0');
 bool conv_w2d_enabled() { return g_w2d && !g_no_wino_policy; }
+// FLOWSE_NO_SMALLM=1: small images run the split-K flat / F(4,3) kernels + reduction launches of rounds 1-4 (A-B hook)
+static const bool g_no_smallm = getenv("FLOWSE_NO_SMALLM") != nullptr;
+bool conv_smallm_ok(int B, int H, int W, int C1, int C2, int Cout, int taps) {
+    if (g_no_smallm || g_force_generic || (taps != 1 && taps != 9) || (C1 % KC) || (C2 % KC) || (Cout % 32) || C1 <= 0) return false;
+    const int64_t M = (int64_t)B * H * W;
+    // (at 2048 pixels -- 16 x 16, batch 8 -- the sliced F(4,3) kernel + its fused reduction / GroupNorm launch measure
+    // equal or better: 5.8 vs 6.2 ms for the level)
+    if (M > 1024 || M < 1) return false;
+    const int64_t cmax = C1 > C2 ? C1 : C2;
+    return (int64_t)(32 + 2 * W + 2) * cmax * 4 < (1LL << 31) && (int64_t)Cout * taps * (C1 + C2) * 4 < (1LL << 31);
+}
 bool conv_force_generic() { return g_force_generic; }
 
 // Winograd plan for a 3x3 shape: 0 = not a Winograd shape (or too small even when sliced), 1 = the Winograd halo
@@ -63,6 +76,7 @@ int f43_plan(int B, int H, int W, int Cin, int Cout, int taps) {
 
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     if (conv_supports_head4(B, H, W, Cin, 0, Cout, taps)) return 1;     // 4-channel heads: dedicated kernel
+    if (conv_smallm_ok(B, H, W, Cin, 0, Cout, taps)) return 1;          // K is split inside the block
     const int64_t M = (int64_t)B * H * W;
     const int bn = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;       // N tile launch_conv picks for this width
     const int bm = conv_small_m(M, Cout) ? 32 : 128;              // M tile (single utterances at the 8x8 / 4x4 levels: 32 rows)
@@ -93,6 +107,7 @@ bool conv_splitk_is_wino(int B, int H, int W, int Cin, int Cout, int taps) {
 bool conv_supports_fused_gn(int B, int H, int W, int C1, int C2, int Cout, int taps) {
     if (conv_supports_head4(B, H, W, C1, C2, Cout, taps)) return true;
     if (g_no_halo || g_force_generic) return false;
+    if (conv_smallm_ok(B, H, W, C1, C2, Cout, taps)) return false;       // takes a materialised (normalised) input
     if (taps != 9 || (H & 7) || (W & 15) || (C1 % KC) || (C2 % KC) || (Cout & 3)) return false;
     const int ks = conv_ksplit(B, H, W, C1 + C2, Cout, taps);
     if (ks != 1 && ks != f43_plan(B, H, W, C1 + C2, Cout, taps)) return false;    // only the Winograd kernel runs split
@@ -148,6 +163,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
     }
     if (a.ksplit <= 1 && !a.partial && !a.bias2 && !a.stats && conv_supports_head4(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))
         return launch_head4(a, s);
+    if (a.wsm && a.ksplit <= 1 && !a.partial && !a.gn.mean && a.out_dt == DT_F32 &&
+        conv_smallm_ok(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))
+        return launch_smallm(a, s);
     if (a.ksplit <= 1 && conv_supports_fused_gn(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
         if (a.wq && (a.Cout % 128) == 0) {
             if (a.terms == 3 && !a.wq_f16) return launch_halo_bf16x3(a, s);

@@ -155,6 +155,10 @@ struct flowse_model {
     float* d_wino2 = nullptr;              // F(4,3) x F(2,3) weights of the same convs (conv3x3_w2d_kernel; FLOWSE_W2D=0: absent)
     int64_t d_wino2_numel = 0;
     std::map<int64_t, int64_t> wino2_of;
+    float* d_wsm16 = nullptr;              // the same in the 16 x 16-tile fragment order (conv_smallm16_kernel), same offsets
+    float* d_wsm = nullptr;                // fragment-order copy of the conv weights with 32-aligned channel counts (conv_smallm_kernel)
+    int64_t d_wsm_numel = 0;
+    std::set<int64_t> wsm_offs;            // packed weight offsets (d_w) that have a copy at the SAME offset in d_wsm
     char* d_ws = nullptr;                  // activation workspace
     size_t d_ws_bytes = 0;
     float* d_ts = nullptr;                 // [N][B] solver times
@@ -203,6 +207,8 @@ struct Packer {
     std::vector<float> host;
     struct WinoReq { int64_t off; int Cout, Cin; };
     std::vector<WinoReq> wino;             // 3x3 convs that also get F(4,3) weights (transformed on the device)
+    struct SmReq { int64_t off; int Cout, Cin, taps; };
+    std::vector<SmReq> smallm;             // convs that also get a fragment-order copy (small-M kernel)
     int64_t put(int64_t n) {
         const int64_t off = ((int64_t)host.size() + 63) & ~(int64_t)63;
         host.resize(off + n, 0.f);

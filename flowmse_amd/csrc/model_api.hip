@@ -194,6 +194,11 @@ static void free_device_state(flowse_model* m) {
     if (m->d_wino2) (void)hipFree(m->d_wino2);
     m->d_wino2 = nullptr;
     m->d_wino2_numel = 0;
+    if (m->d_wsm) (void)hipFree(m->d_wsm);
+    if (m->d_wsm16) (void)hipFree(m->d_wsm16);
+    m->d_wsm16 = nullptr;
+    m->d_wsm = nullptr;
+    m->d_wsm_numel = 0;
     if (m->d_call) (void)hipFree(m->d_call);
     if (m->d_rk) (void)hipFree(m->d_rk);
     m->d_rk = nullptr;
@@ -441,6 +446,28 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
         float* dst = m->d_wino + m->wino_of[r.off];
         const int wrc = launch_f43_weights(m->d_w + r.off, r.Cout, r.Cin, dst, nullptr);
         if (wrc != OK) return wrc;
+    }
+    // fragment-order copies for the small-M kernel (fp32 activations only), at the same offsets as in d_w
+    m->wsm_offs.clear();
+    if (!m->storage16() && !pk.smallm.empty() && conv_smallm_ok(1, 4, 4, 32, 0, 32, 1)) {
+        const int64_t nw = (int64_t)pk.host.size();
+        if (m->d_wsm && m->d_wsm_numel < nw) {
+            FLOWSE_HIP(hipFree(m->d_wsm));
+            FLOWSE_HIP(hipFree(m->d_wsm16));
+            m->d_wsm = m->d_wsm16 = nullptr;
+        }
+        if (!m->d_wsm) {
+            FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_wsm), nw * sizeof(float)));
+            FLOWSE_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_wsm16), nw * sizeof(float)));
+            m->d_wsm_numel = nw;
+        }
+        for (auto& r : pk.smallm) {
+            if ((int64_t)r.Cout * r.taps * r.Cin * 4 >= (1LL << 31)) continue;
+            int src = launch_smallm_weights(m->d_w + r.off, r.Cout, r.taps, r.Cin, m->d_wsm + r.off, nullptr);
+            if (src == OK) src = launch_smallm_weights(m->d_w + r.off, r.Cout, r.taps, r.Cin, m->d_wsm16 + r.off, nullptr, true);
+            if (src != OK) return src;
+            m->wsm_offs.insert(r.off);
+        }
     }
     // F(4,3) x F(2,3) weights of the same convs (the two-dimensional kernel takes the large images)
     m->wino2_of.clear();
@@ -739,6 +766,7 @@ int flowse_upfirdn2d(const float* input, const float* kernel, int planes, int in
 }
 
 int64_t flowse_op_conv2d_scratch_floats(int B, int H, int W, int Cin, int Cout, int taps) {
+    if (conv_smallm_ok(B, H, W, Cin, 0, Cout, taps)) return (int64_t)Cout * taps * Cin;     // fragment-order weight copy
     const int ks = conv_ksplit(B, H, W, Cin, Cout, taps);
     return ks > 1 ? (int64_t)ks * B * H * W * Cout : 0;
 }
@@ -756,7 +784,13 @@ int flowse_op_conv2d(const float* in1, int C1, const float* in2, int C2, const f
     c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = taps; c.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (C1 == 4 && !in2) return launch_conv_cin4(c, s);
-    if (splitk_scratch) {
+    if (splitk_scratch && conv_smallm_ok(B, H, W, c.C1, c.C2, Cout, taps)) {   // the model handle's kernel for this shape
+        const bool t16 = conv_smallm_tile16(B, H, W);
+        const int rc = launch_smallm_weights(w, Cout, taps, c.C1 + c.C2, splitk_scratch, s, t16);
+        if (rc != OK) return rc;
+        c.wsm = splitk_scratch;
+        c.wsm16 = t16 ? splitk_scratch : nullptr;
+    } else if (splitk_scratch) {
         c.ksplit = conv_ksplit(B, H, W, c.C1 + c.C2, Cout, taps);
         c.partial = c.ksplit > 1 ? splitk_scratch : nullptr;
     }

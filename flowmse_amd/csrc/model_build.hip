@@ -201,6 +201,7 @@ static int64_t pack_conv(Packer& pk, const float* src, int Cout, int Cin, int ta
             for (int t = 0; t < taps; ++t)
                 dst[((int64_t)co * taps + t) * Cin + ci] = src[((int64_t)co * Cin + ci) * taps + t];
     if (taps == 9 && (Cin % 32) == 0 && (Cout % 64) == 0) pk.wino.push_back({off, Cout, Cin});
+    if ((Cin % 32) == 0 && (Cout % 32) == 0) pk.smallm.push_back({off, Cout, Cin, taps});
     return off;
 }
 static int64_t pack_copy(Packer& pk, const float* src, int64_t n) {

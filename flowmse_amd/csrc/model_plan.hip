@@ -214,6 +214,11 @@ struct Builder {
                                                                                  : conv16_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps))
                              : conv_fused_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps);
         if (cin4 && !out_is_res && C1 == 4 && !has2 && conv_cin4_uses_mfma(Bn, H, Wd, Cout, taps)) st_nblk = H * Wd / 128;
+        // conv_ksplit / conv_fused_stats_blocks judge the small-M kernel by the TOTAL channel count; a concat whose parts are
+        // not 32-aligned (not in the released net) runs the unsplit flat kernel instead: its statistics geometry applies
+        const bool use_smallm = !in16 && !cin4 && M->wsm_offs.count(w) && conv_smallm_ok(Bn, H, Wd, C1, C2, Cout, taps);
+        if (!in16 && !cin4 && !use_smallm && st_nblk > 0 && conv_smallm_ok(Bn, H, Wd, C1 + C2, 0, Cout, taps))
+            st_nblk = (H * Wd) % 128 == 0 ? H * Wd / 128 : 0;
         // the two-dimensional Winograd kernel takes this launch: statistics in 4 x 16 pixel strips
         const auto w2_it = M->wino2_of.find(w);
         const int64_t wino2_off = (!in16 && taps == 9 && !cin4 && ks == 1 && w2_it != M->wino2_of.end() &&
@@ -282,6 +287,10 @@ struct Builder {
             }
             if (wino_off >= 0) c.wino = M->d_wino + wino_off;
             if (wino2_off >= 0) c.wino2 = M->d_wino2 + wino2_off;
+            if (use_smallm) {
+                c.wsm = M->d_wsm + w;
+                c.wsm16 = M->d_wsm16 + w;
+            }
             return c;
         };
         const double flops = 2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2);
