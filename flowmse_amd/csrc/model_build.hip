@@ -289,6 +289,11 @@ int pack_weights(flowse_model* m, const float* blob, Packer& pk) {
                 for (int o = 0; o < C; ++o)
                     for (int i = 0; i < C; ++i) pk.host[mod.w_o + (int64_t)o * C + i] = W3[(int64_t)i * C + o];
                 mod.w_o_b = pack_copy(pk, P(p + 9), C);
+                // the two projections are 1x1 convs: fragment-order copies for the small-M kernel (single utterances)
+                if ((C % 32) == 0) {
+                    pk.smallm.push_back({mod.w_qkv, 3 * C, C, 1});
+                    pk.smallm.push_back({mod.w_o, C, C, 1});
+                }
                 break;
             }
         }
