@@ -300,7 +300,7 @@ inline int64_t conv_w2d_numel(int Cout, int Cin) { return (int64_t)Cout * 24 * C
 // ConvArgs::wino2 is set); conv_supports_w2d: ... and the policy wants it (enough blocks to fill the chip): the plan's test
 bool conv_w2d_shape_ok(int B, int H, int W, int C1, int C2, int Cout, int taps);
 bool conv_supports_w2d(int B, int H, int W, int C1, int C2, int Cout, int taps);
-// small-M kernel (conv_smallm.hip): shapes it takes (<= 1024 pixels in the batch, channel counts multiples of 32; honours
+// small-M kernel (conv_smallm.hip): shapes it takes (<= 2048 pixels in the batch, channel counts multiples of 32; honours
 // FLOWSE_NO_SMALLM=1), its weight copy and statistics geometry
 bool conv_smallm_ok(int B, int H, int W, int C1, int C2, int Cout, int taps);
 int launch_smallm_weights(const float* w_packed, int Cout, int taps, int Cin, float* out, hipStream_t s, bool tile16 = false);

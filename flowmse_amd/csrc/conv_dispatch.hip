@@ -45,12 +45,13 @@ static const bool g_w2d = !(getenv("FLOWSE_W2D") && getenv("FLOWSE_W2D")[0] == '
 bool conv_w2d_enabled() { return g_w2d && !g_no_wino_policy; }
 // FLOWSE_NO_SMALLM=1: small images run the split-K flat / F(4,3) kernels + reduction launches of rounds 1-4 (A-B hook)
 static const bool g_no_smallm = getenv("FLOWSE_NO_SMALLM") != nullptr;
+static const int g_smallm_max = getenv("FLOWSE_SMALLM_MAX") ? atoi(getenv("FLOWSE_SMALLM_MAX")) : 2048;
 bool conv_smallm_ok(int B, int H, int W, int C1, int C2, int Cout, int taps) {
     if (g_no_smallm || g_force_generic || (taps != 1 && taps != 9) || (C1 % KC) || (C2 % KC) || (Cout % 32) || C1 <= 0) return false;
     const int64_t M = (int64_t)B * H * W;
-    // (at 2048 pixels -- 16 x 16, batch 8 -- the sliced F(4,3) kernel + its fused reduction / GroupNorm launch measure
-    // equal or better: 5.8 vs 6.2 ms for the level)
-    if (M > 1024 || M < 1) return false;
+    // (2048 pixels = 16 x 16 at batch 8: 4.96 vs 5.76 ms for the level against the sliced F(4,3) kernel + reduction launches,
+    // A-B-A-B on one box; FLOWSE_SMALLM_MAX moves the limit)
+    if (M > g_smallm_max || M < 1) return false;
     const int64_t cmax = C1 > C2 ? C1 : C2;
     return (int64_t)(32 + 2 * W + 2) * cmax * 4 < (1LL << 31) && (int64_t)Cout * taps * (C1 + C2) * 4 < (1LL << 31);
 }

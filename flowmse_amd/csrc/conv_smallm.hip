@@ -1,6 +1,6 @@
 // Replaces (reference): ddpm_conv3x3 / ddpm_conv1x1 (flowmse/backbones/ncsnpp_utils/layers.py:100-124) and NIN (:546-555) on
 // the SMALL images of the network (ncsnpp.py:289-330, 335-385 at the 16 x 16 ... 4 x 4 levels; 32 x 32 for a single
-// utterance): at most 1024 pixels in the whole batch.
+// utterance): at most 2048 pixels in the whole batch.
 #include "conv_common.h"
 
 namespace flowse {
@@ -8,7 +8,7 @@ namespace flowse {
 // ---------------------------------------------------------------------------------------------------
 // Small-M implicit GEMM with the K split INSIDE the block.
 //
-// With M = B H W <= 1024 pixels a 128 x 128 tiling has at most 8 tiles, so rounds 1-4 sliced K over extra blocks: every
+// With M = B H W <= 2048 pixels a 128 x 128 tiling has at most 16 tiles, so rounds 1-4 sliced K over extra blocks: every
 // slice wrote a raw fp32 partial tile ([ksplit][M][Cout] slab: 33 MB for a 2 MB result at 16 x 16, batch 8) and a second
 // launch read the slabs back, summed them and ran the epilogue -- 40 us per convolution against an MFMA floor of 8-15.
 // Here a block owns a 32-pixel x (32 or 64)-channel output tile (256 blocks at 2048 pixels x 256 channels: one per CU)
