@@ -618,7 +618,8 @@ np.savez({dst!r}, **out)
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("switch", ["FLOWSE_NO_WINOGRAD", "FLOWSE_NO_HALO_CONV", "FLOWSE_FORCE_GENERIC_CONV", "FLOWSE_GRAPH"])
+@pytest.mark.parametrize("switch", ["FLOWSE_NO_WINOGRAD", "FLOWSE_NO_HALO_CONV", "FLOWSE_FORCE_GENERIC_CONV", "FLOWSE_GRAPH",
+                                    "FLOWSE_NO_SMALLM", "FLOWSE_W2D=0"])
 def test_library_switches_keep_parity(tmp_path, switch):
     """Every environment switch that selects a different kernel path (read once per process, hence a child process):
     the tiny sampler and the wide (non-power-of-two channel) forward still match the REFERENCE's golden outputs."""
@@ -629,7 +630,8 @@ def test_library_switches_keep_parity(tmp_path, switch):
     root = os.path.dirname(tests)
     dst = str(tmp_path / "out.npz")
     env = dict(os.environ)
-    env[switch] = "1"
+    name, _, val = switch.partition("=")
+    env[name] = val or "1"
     r = subprocess.run([sys.executable, "-c", _ENV_CHILD.format(tests=tests, root=root, dst=dst)], env=env,
                        capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stderr[-3000:]

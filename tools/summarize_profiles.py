@@ -64,7 +64,7 @@ def main(tag):
         out[k[:120]] = {"launches": n, "FETCH_SIZE_KB_per_launch_raw": fs / n,
                         "WRITE_SIZE_KB_per_launch": ws / n,
                         "hbm_bytes_per_launch": (2.0 * fs + ws) * 1024.0 / n}
-    dom = ([k for k in out if "conv3x3_f43_kernel<2, false, 2>" in k] or [k for k in out if "conv3x3_f43_kernel<2, false>" in k] or [k for k in out if "conv3x3_f43_kernel<2>" in k] or
+    dom = ([k for k in out if "conv3x3_w2d_kernel<2>" in k] or [k for k in out if "conv3x3_f43_kernel<2, false, 2>" in k] or [k for k in out if "conv3x3_f43_kernel<2, false>" in k] or [k for k in out if "conv3x3_f43_kernel<2>" in k] or
            [k for k in out if "conv3x3_wino_kernel<2>" in k] or
            [k for k in out if "conv3x3_halo_kernel<2, 2, 2, 2, 2>" in k])
     summary = {"unit_note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving correction)",
