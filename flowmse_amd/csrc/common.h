@@ -291,7 +291,10 @@ int launch_convert(const void* src, int src_dt, void* dst, int dst_dt, int64_t n
 // F(4,3) Winograd weight transform along the kernel's vertical axis, packed [Cout][9][Cin] -> fragment order, on device
 int launch_f43_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s);
 // [Cout][9][Cin] 16-bit weights -> MFMA fragment order for conv3x3_pc16_kernel (same element count)
-int launch_pc16_weights(const void* w16, int Cout, int Cin, void* dst, hipStream_t s);
+int launch_pc16_weights(const void* w16, int Cout, int Cin, void* dst, hipStream_t s, int taps = 9);
+// 16-bit small-image kernel (conv16_smallm.hip): shapes it takes, its statistics geometry (blocks of min(32, H W) pixels)
+bool conv16_smallm_ok(int B, int H, int W, int C1, int C2, int Cout, int taps);
+int conv16_smallm_stats_blocks(int B, int H, int W);
 inline int64_t conv_wino_numel(int Cout, int Cin) { return (int64_t)Cout * 18 * Cin; }
 // F(4,3) x F(2,3) weight transform, packed [Cout][9][Cin] -> fragment order [Cout/32][h][Cin/32][6][4][64][4], on device
 int launch_w2d_weights(const float* w_packed, int Cout, int Cin, float* out, hipStream_t s);

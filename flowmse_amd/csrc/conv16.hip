@@ -424,6 +424,7 @@ bool conv16_uses_halo(int B, int H, int W, int C1, int C2, int Cout, int taps) {
 }
 
 int conv16_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
+    if (conv16_smallm_ok(B, H, W, Cin, 0, Cout, taps)) return 1;        // K is split inside the block (conv16_smallm.hip)
     const int64_t M = (int64_t)B * H * W;
     const int64_t tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
     const int stages = ((Cin / KC) * taps + 1) / 2;
@@ -439,6 +440,7 @@ int conv16_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps) {
     const int HW = H * W;
     if (Cout & 3) return 0;
     if (taps == 9 && conv16_uses_halo(B, H, W, Cin, 0, Cout, taps)) return HW / 128;     // C1/C2 split is irrelevant here
+    if (conv16_smallm_ok(B, H, W, Cin, 0, Cout, taps)) return conv16_smallm_stats_blocks(B, H, W);
     if (conv16_ksplit(B, H, W, Cin, Cout, taps) != 1) {
         const int PB = sk_pixels_per_block(HW);
         return ((HW % PB) == 0 && Cout / 4 <= 256) ? HW / PB : 0;

@@ -633,34 +633,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
 
 // Weights of a 3x3 conv in MFMA fragment order for the consumers of conv3x3_pc16_kernel:
 //   dst[nb][chunk][tap][mh][lane = kh * 32 + li][8] = w[nb * 32 + li][tap][chunk * 32 + mh * 16 + kh * 8 + 0..7]
-// (w = [Cout][9][Cin] in the 16-bit operand type), i.e. one 1 KB line per wave-level B operand of v_mfma_f32_32x32x16.
+// (w = [Cout][taps][Cin] in the 16-bit operand type; taps = 1: the 1x1 convs, for the 16-bit small-image kernel), i.e. one 1 KB line per wave-level B operand of v_mfma_f32_32x32x16.
 __global__ __launch_bounds__(256) void pc16_weights_kernel(const uint16_t* __restrict__ w, int Cout, int Cin,
-                                                          uint16_t* __restrict__ dst) {
+                                                          uint16_t* __restrict__ dst, int taps) {
     const int nchunks = Cin / KC;
-    const int64_t n16 = (int64_t)Cout * 9 * Cin / 8;       // 16-byte units
+    const int64_t n16 = (int64_t)Cout * taps * Cin / 8;    // 16-byte units
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= n16) return;
     const int lane = (int)(u & 63);
     int64_t r = u >> 6;
     const int mh = (int)(r & 1);
     r >>= 1;
-    const int tap = (int)(r % 9);
-    r /= 9;
+    const int tap = (int)(r % taps);
+    r /= taps;
     const int chunk = (int)(r % nchunks);
     const int nb = (int)(r / nchunks);
     const int li = lane & 31, kh = lane >> 5;
-    const uint16_t* src = w + ((int64_t)(nb * 32 + li) * 9 + tap) * Cin + chunk * KC + mh * 16 + kh * 8;
+    const uint16_t* src = w + ((int64_t)(nb * 32 + li) * taps + tap) * Cin + chunk * KC + mh * 16 + kh * 8;
     *reinterpret_cast<uint4*>(dst + u * 8) = *reinterpret_cast<const uint4*>(src);
 }
 
-int launch_pc16_weights(const void* w16, int Cout, int Cin, void* dst, hipStream_t s) {
-    if ((Cin % KC) || (Cout % 32) || (int64_t)Cout * 9 * Cin * 2 >= (1LL << 31)) {
+int launch_pc16_weights(const void* w16, int Cout, int Cin, void* dst, hipStream_t s, int taps) {
+    if ((Cin % KC) || (Cout % 32) || (taps != 1 && taps != 9) || (int64_t)Cout * taps * Cin * 2 >= (1LL << 31)) {
         set_error("pc16_weights: unsupported Cout=%d Cin=%d", Cout, Cin);
         return ERR_SHAPE;
     }
-    const int64_t n16 = (int64_t)Cout * 9 * Cin / 8;
+    const int64_t n16 = (int64_t)Cout * taps * Cin / 8;
     hipLaunchKernelGGL(pc16_weights_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s,
-                       static_cast<const uint16_t*>(w16), Cout, Cin, static_cast<uint16_t*>(dst));
+                       static_cast<const uint16_t*>(w16), Cout, Cin, static_cast<uint16_t*>(dst), taps);
     FLOWSE_LAUNCH_CHECK();
     return OK;
 }

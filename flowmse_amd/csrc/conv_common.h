@@ -31,6 +31,7 @@ int launch_w2d(const ConvArgs& a, hipStream_t s);              // conv_w2d.hip: 
 int launch_halo_bf16x3(const ConvArgs& a, hipStream_t s);      // conv16.hip: split-bf16 operands, fp32 storage
 int launch_halo16_any(const ConvArgs& a, hipStream_t s);       // conv16.hip: 16-bit operands, LDS-halo 3x3
 int launch_flat16(const ConvArgs& a, hipStream_t s);           // conv16.hip: 16-bit storage, flat 1x1 / small 3x3
+int launch_smallm16b(const ConvArgs& a, hipStream_t s);        // conv16_smallm.hip: 16-bit storage, <= 2048 pixels, K split inside the block
 int launch_pc16(const ConvArgs& a, hipStream_t s);             // conv16_pc.hip: 16-bit storage, producer / consumer LDS-halo 3x3
 
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with its own

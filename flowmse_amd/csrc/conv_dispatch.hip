@@ -154,6 +154,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
             if (a.wfrag && conv16_uses_pc(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) return launch_pc16(a, s);
             return launch_halo16_any(a, s);
         }
+        if (a.wfrag && a.ksplit <= 1 && !a.partial && !a.gn.mean && (a.out_dt == a.in_dt || a.out_dt == DT_F32) &&
+            conv16_smallm_ok(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))
+            return launch_smallm16b(a, s);
         if (a.ksplit > 1 && !a.partial) {
             set_error("conv: split-K needs a partial buffer");
             return ERR_ARG;

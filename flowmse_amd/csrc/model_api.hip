@@ -425,6 +425,16 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
             if (frc != OK) return frc;
             m->frag_offs.insert(r.off);
         }
+        // ... and for every other conv with 32-aligned channel counts (1x1 shortcuts, attention projections, 3x3 with
+        // Cout % 128 != 0): the 16-bit small-image kernel reads the same layout
+        if (conv16_smallm_ok(1, 4, 4, 32, 0, 32, 1)) {
+            for (auto& r : pk.smallm) {
+                if (m->frag_offs.count(r.off) || (int64_t)r.Cout * r.taps * r.Cin * 2 >= (1LL << 31)) continue;
+                const int frc = launch_pc16_weights(m->d_w16 + r.off, r.Cout, r.Cin, m->d_wfrag + r.off, nullptr, r.taps);
+                if (frc != OK) return frc;
+                m->frag_offs.insert(r.off);
+            }
+        }
         pk.wino.clear();                     // no fp32 Winograd kernels run on 16-bit activations
     }
     // F(4,3) Winograd weights, derived on the device from the packed fp32 weights just uploaded
@@ -964,7 +974,7 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
     void* a1 = take(2 * M * C1);
     void* a2 = C2 ? take(2 * M * C2) : nullptr;
     void* wq = take(2 * nw);
-    const bool frag = taps == 9 && conv16_uses_pc(B, H, W, C1, C2, Cout, taps);
+    const bool frag = (taps == 9 && conv16_uses_pc(B, H, W, C1, C2, Cout, taps)) || conv16_smallm_ok(B, H, W, C1, C2, Cout, taps);
     void* wfrag = frag ? take(2 * nw) : nullptr;
     void* r16 = res ? take(2 * M * Cout) : nullptr;
     void* o16 = take(2 * M * Cout);
@@ -976,7 +986,7 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
     int rc = launch_convert(in1, DT_F32, a1, dt, M * C1, s);
     if (rc == OK && C2) rc = launch_convert(in2, DT_F32, a2, dt, M * C2, s);
     if (rc == OK) rc = launch_convert(w, DT_F32, wq, dt, nw, s);
-    if (rc == OK && frag) rc = launch_pc16_weights(wq, Cout, (int)C, wfrag, s);
+    if (rc == OK && frag) rc = launch_pc16_weights(wq, Cout, (int)C, wfrag, s, taps);
     if (rc == OK && res) rc = launch_convert(res, DT_F32, r16, dt, M * Cout, s);
     if (rc != OK) return rc;
     ConvArgs c;

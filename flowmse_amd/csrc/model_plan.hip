@@ -219,6 +219,9 @@ struct Builder {
         const bool use_smallm = !in16 && !cin4 && M->wsm_offs.count(w) && conv_smallm_ok(Bn, H, Wd, C1, C2, Cout, taps);
         if (!in16 && !cin4 && !use_smallm && st_nblk > 0 && conv_smallm_ok(Bn, H, Wd, C1 + C2, 0, Cout, taps))
             st_nblk = (H * Wd) % 128 == 0 ? H * Wd / 128 : 0;
+        if (in16 && !cin4 && st_nblk > 0 && conv16_smallm_ok(Bn, H, Wd, C1 + C2, 0, Cout, taps) &&
+            !(M->frag_offs.count(w) && conv16_smallm_ok(Bn, H, Wd, C1, C2, Cout, taps)))
+            st_nblk = (H * Wd) % 128 == 0 ? H * Wd / 128 : 0;
         // the two-dimensional Winograd kernel takes this launch: statistics in 4 x 16 pixel strips
         const auto w2_it = M->wino2_of.find(w);
         const int64_t wino2_off = (!in16 && taps == 9 && !cin4 && ks == 1 && w2_it != M->wino2_of.end() &&

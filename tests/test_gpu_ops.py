@@ -148,7 +148,7 @@ WINO_CASES = [
     (1, 256, 128, 64, 0, 64, False, True, 1.0, True),
     (8, 32, 32, 256, 256, 256, True, True, 0.70710678, True),   # one block per CU: preferred over split-K
     (2, 72, 256, 64, 32, 128, True, True, 1.0, True),           # H = 9 tiles (odd), 64+32 concat, strip-major walk
-    (8, 16, 16, 256, 0, 256, True, True, 0.70710678, True),     # 64 blocks: F(4,3) split over 4 slices of chunks
+    (8, 16, 32, 256, 0, 256, True, True, 0.70710678, True),     # 128 blocks: F(4,3) split over 4 slices of chunks (above the small-M kernel's 2048 pixels)
     (1, 64, 64, 256, 256, 256, True, False, 1.0, True),         # single utterance: 128 blocks, split 4 x 4 chunks
     (8, 64, 128, 128, 0, 128, True, True, 0.70710678, True),    # 512 blocks of 128 channels: the F(4,3) 128-channel block form
     (2, 128, 128, 128, 128, 256, True, True, 1.0, True),        # same form, two channel blocks, concat input
