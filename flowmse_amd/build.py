@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflowse_hip.so")
 SOURCES = ["model_build.hip", "model_plan.hip", "model_api.hip", "conv_dispatch.hip", "conv_f43.hip", "conv_w2d.hip", "conv_halo.hip",
-           "conv_flat.hip", "conv_smallm.hip", "conv_reduce.hip", "conv16.hip", "conv16_pc.hip", "conv16_smallm.hip", "norm.hip", "fir.hip", "attention.hip", "misc.hip", "spec.hip"]
+           "conv_flat.hip", "conv_1x1.hip", "conv_smallm.hip", "conv_reduce.hip", "conv16.hip", "conv16_pc.hip", "conv16_smallm.hip", "norm.hip", "fir.hip", "attention.hip", "misc.hip", "spec.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"] + os.environ.get("FLOWSE_BUILD_FLAGS", "").split()   # extra flags for A-B builds (tools/build_variants.py)
 

@@ -309,6 +309,9 @@ bool conv_smallm_ok(int B, int H, int W, int C1, int C2, int Cout, int taps);
 int launch_smallm_weights(const float* w_packed, int Cout, int taps, int Cin, float* out, hipStream_t s, bool tile16 = false);
 bool conv_smallm_tile16(int B, int H, int W);
 int conv_smallm_stats_blocks(int B, int H, int W);
+// streaming fp32 1x1 kernel (conv_1x1.hip): shapes it takes, its statistics geometry (blocks of 256 pixels)
+bool conv1x1_stream_ok(int B, int H, int W, int C1, int C2, int Cout, int taps);
+int conv1x1_stream_stats_blocks(int B, int H, int W);
 bool conv_w2d_enabled();                   // FLOWSE_W2D (read once): the model handle keeps the 2-D weights and uses the kernel
 bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps);
 // whole-K F(4,3) launches of this shape use 128-channel blocks (conv3x3_f43_kernel<GN, false, 2>)

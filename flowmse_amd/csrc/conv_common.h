@@ -26,6 +26,7 @@ int launch_flat_fp32(const ConvArgs& a, hipStream_t s);        // conv_flat.hip:
 int launch_halo_fp32(const ConvArgs& a, hipStream_t s);        // conv_halo.hip: direct LDS-halo 3x3 (exact fmaf chain)
 int launch_head4(const ConvArgs& a, hipStream_t s);            // conv_halo.hip: 3x3 to four output channels
 int launch_f43(const ConvArgs& a, hipStream_t s);              // conv_f43.hip: F(4,3) Winograd 3x3 (whole K or slices)
+int launch_1x1_stream(const ConvArgs& a, hipStream_t s);       // conv_1x1.hip: fp32 1x1 on large images, every wave its own GEMM
 int launch_smallm(const ConvArgs& a, hipStream_t s);           // conv_smallm.hip: <= 2048 pixels, K split inside the block
 int launch_w2d(const ConvArgs& a, hipStream_t s);              // conv_w2d.hip: F(4,3) x F(2,3) Winograd 3x3 (whole K, large images)
 int launch_halo_bf16x3(const ConvArgs& a, hipStream_t s);      // conv16.hip: split-bf16 operands, fp32 storage

@@ -9,6 +9,7 @@
 //   conv_halo.hip     direct fp32 LDS-halo 3x3, 4-channel heads / input layers
 //   conv_flat.hip     flat fp32 kernels: 1x1, small 3x3, split-K slices
 //   conv_smallm.hip   fp32 convs on <= 2048 pixels: K split inside the block (no slab, no reduction launch)
+//   conv_1x1.hip      fp32 1x1 on large images: every wave its own GEMM, operands straight into fragment registers
 //   conv_reduce.hip   second pass of split-K launches (+ fused GroupNorm statistics / GroupNorm)
 //   conv16.hip        16-bit operand / storage modes
 // Replaces (reference): ddpm_conv3x3 / ddpm_conv1x1 (flowmse/backbones/ncsnpp_utils/layers.py:100-124), NIN (:546-555).
@@ -27,6 +28,7 @@ int conv_fused_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps) {
     const int HW = H * W;
     if (Cout & 3) return 0;
     if (conv_smallm_ok(B, H, W, Cin, 0, Cout, taps)) return conv_smallm_stats_blocks(B, H, W);
+    if (conv1x1_stream_ok(B, H, W, Cin, 0, Cout, taps)) return conv1x1_stream_stats_blocks(B, H, W);
     if (conv_ksplit(B, H, W, Cin, Cout, taps) != 1) {      // statistics come from the split-K reduction
         const int PB = sk_pixels_per_block(HW);
         return ((HW % PB) == 0 && Cout / 4 <= 256) ? HW / PB : 0;
@@ -170,6 +172,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
     if (a.wsm && a.ksplit <= 1 && !a.partial && !a.gn.mean && a.out_dt == DT_F32 &&
         conv_smallm_ok(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))
         return launch_smallm(a, s);
+    if (a.wsm && a.ksplit <= 1 && !a.partial && !a.gn.mean && a.out_dt == DT_F32 &&
+        conv1x1_stream_ok(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))
+        return launch_1x1_stream(a, s);
     if (a.ksplit <= 1 && conv_supports_fused_gn(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
         if (a.wq && (a.Cout % 128) == 0) {
             if (a.terms == 3 && !a.wq_f16) return launch_halo_bf16x3(a, s);

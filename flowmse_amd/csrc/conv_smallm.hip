@@ -134,7 +134,9 @@ __global__ __launch_bounds__(512, 2) void conv_smallm_kernel(ConvArgs a) {
         auto step = [&](auto dc) {
             constexpr int d = decltype(dc)::value;
             gload(wave + 8 * (i + d + D - 1), std::integral_constant<int, (d + D - 1) % D>{});
+            __builtin_amdgcn_sched_barrier(0);            // (hipcc otherwise sinks the requests down to their first use)
             compute(dc);
+            __builtin_amdgcn_sched_barrier(0);
         };
         sm_unroll(step, std::make_integer_sequence<int, D>{});
     }
@@ -317,7 +319,9 @@ __global__ __launch_bounds__(512, 2) void conv_smallm16_kernel(ConvArgs a) {
         auto step = [&](auto dc) {
             constexpr int d = decltype(dc)::value;
             gload(wave + 8 * (i + d + D - 1), std::integral_constant<int, (d + D - 1) % D>{});
+            __builtin_amdgcn_sched_barrier(0);            // (hipcc otherwise sinks the requests down to their first use)
             compute(dc);
+            __builtin_amdgcn_sched_barrier(0);
         };
         sm_unroll(step, std::make_integer_sequence<int, D>{});
     }

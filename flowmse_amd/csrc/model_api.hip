@@ -776,7 +776,8 @@ int flowse_upfirdn2d(const float* input, const float* kernel, int planes, int in
 }
 
 int64_t flowse_op_conv2d_scratch_floats(int B, int H, int W, int Cin, int Cout, int taps) {
-    if (conv_smallm_ok(B, H, W, Cin, 0, Cout, taps)) return (int64_t)Cout * taps * Cin;     // fragment-order weight copy
+    if (conv_smallm_ok(B, H, W, Cin, 0, Cout, taps) || conv1x1_stream_ok(B, H, W, Cin, 0, Cout, taps))
+        return (int64_t)Cout * taps * Cin;                                                  // fragment-order weight copy
     const int ks = conv_ksplit(B, H, W, Cin, Cout, taps);
     return ks > 1 ? (int64_t)ks * B * H * W * Cout : 0;
 }
@@ -794,7 +795,11 @@ int flowse_op_conv2d(const float* in1, int C1, const float* in2, int C2, const f
     c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = taps; c.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (C1 == 4 && !in2) return launch_conv_cin4(c, s);
-    if (splitk_scratch && conv_smallm_ok(B, H, W, c.C1, c.C2, Cout, taps)) {   // the model handle's kernel for this shape
+    if (splitk_scratch && conv1x1_stream_ok(B, H, W, c.C1, c.C2, Cout, taps)) {   // the model handle's kernel for this shape
+        const int rc = launch_smallm_weights(w, Cout, taps, c.C1 + c.C2, splitk_scratch, s, false);
+        if (rc != OK) return rc;
+        c.wsm = splitk_scratch;
+    } else if (splitk_scratch && conv_smallm_ok(B, H, W, c.C1, c.C2, Cout, taps)) {
         const bool t16 = conv_smallm_tile16(B, H, W);
         const int rc = launch_smallm_weights(w, Cout, taps, c.C1 + c.C2, splitk_scratch, s, t16);
         if (rc != OK) return rc;

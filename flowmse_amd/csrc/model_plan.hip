@@ -219,6 +219,9 @@ struct Builder {
         const bool use_smallm = !in16 && !cin4 && M->wsm_offs.count(w) && conv_smallm_ok(Bn, H, Wd, C1, C2, Cout, taps);
         if (!in16 && !cin4 && !use_smallm && st_nblk > 0 && conv_smallm_ok(Bn, H, Wd, C1 + C2, 0, Cout, taps))
             st_nblk = (H * Wd) % 128 == 0 ? H * Wd / 128 : 0;
+        const bool use_stream = !in16 && !cin4 && ks == 1 && M->wsm_offs.count(w) && conv1x1_stream_ok(Bn, H, Wd, C1, C2, Cout, taps);
+        if (!in16 && !cin4 && !use_stream && st_nblk > 0 && conv1x1_stream_ok(Bn, H, Wd, C1 + C2, 0, Cout, taps))
+            st_nblk = (H * Wd) % 128 == 0 ? H * Wd / 128 : 0;
         if (in16 && !cin4 && st_nblk > 0 && conv16_smallm_ok(Bn, H, Wd, C1 + C2, 0, Cout, taps) &&
             !(M->frag_offs.count(w) && conv16_smallm_ok(Bn, H, Wd, C1, C2, Cout, taps)))
             st_nblk = (H * Wd) % 128 == 0 ? H * Wd / 128 : 0;
@@ -294,6 +297,7 @@ struct Builder {
                 c.wsm = M->d_wsm + w;
                 c.wsm16 = M->d_wsm16 + w;
             }
+            if (use_stream) c.wsm = M->d_wsm + w;
             return c;
         };
         const double flops = 2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2);

@@ -75,6 +75,41 @@ SPLITK_CASES = [
 ]
 
 
+STREAM_CASES = [
+    # B, H, W, C1, C2, Cout, bias, bias2, res, scale      (1x1, > 2048 pixels, >= 256 blocks of 256 pixels x 128 channels)
+    (8, 64, 64, 256, 256, 256, True, False, False, 1.0),          # shortcut on concat 512 -> 256: two channel blocks
+    (4, 128, 128, 128, 128, 128, True, True, True, 0.70710678),   # per-sample bias and residual through the direct stores
+    (1, 256, 256, 128, 0, 128, False, False, False, 1.0),         # one utterance at the top level
+    (2, 128, 256, 32, 0, 128, True, False, True, 1.0),            # one chunk (K = 32)
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES)
+def test_conv1x1_stream(G, case):
+    """The streaming fp32 1x1 kernel (every wave its own GEMM, operands straight into fragment registers) against torch's
+    fp32 conv and against the flat kernel on the same input (the op entry runs it when given the weight-copy scratch)."""
+    B, H, W, C1, C2, Cout, has_b, has_b2, has_res, scale = case
+    x1 = rnd(1, (B, C1, H, W))
+    x2 = rnd(2, (B, C2, H, W)) if C2 else None
+    w = rnd(3, (Cout, C1 + C2, 1, 1), (1.0 / (C1 + C2)) ** 0.5)
+    bias = rnd(4, (Cout,), 0.1) if has_b else None
+    bias2 = rnd(5, (B, Cout + 8), 0.1) if has_b2 else None
+    res = rnd(6, (B, Cout, H, W)) if has_res else None
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    ref = F.conv2d(xin.double(), w.double(), bias.double() if has_b else None).float()
+    if has_b2:
+        ref = ref + bias2[:, :Cout, None, None]
+    if has_res:
+        ref = ref + res
+    ref = ref * scale
+    got = G.conv2d(x1, w, bias, x2, bias2, res, scale, splitk=True)
+    assert G.conv2d.last_split, "no weight-copy scratch requested: the streaming kernel did not take this shape"
+    err = C.rel_l2(got, ref)
+    flat = G.conv2d(x1, w, bias, x2, bias2, res, scale)
+    print(f"1x1 stream rel-L2 {err:.2e}   flat kernel {C.rel_l2(flat, ref):.2e}")
+    assert err < TOL and torch.equal(got, G.conv2d(x1, w, bias, x2, bias2, res, scale, splitk=True))
+
+
 @pytest.mark.parametrize("case", SPLITK_CASES)
 def test_conv2d_splitk(G, case):
     B, H, W, C1, C2, Cout, k, has_b, has_b2, has_res, scale = case
