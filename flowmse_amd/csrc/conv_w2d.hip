@@ -605,14 +605,17 @@ int launch_w2d_weights(const float* w_packed, int Cout, int Cin, float* out, hip
     return OK;
 }
 
-// tiles per block: as many (8, 4, 2) as still leave two full rounds of 256 blocks (one per CU), so that the prologue
-// is paid once per block; needs an even chunk count and must divide the tiles of an image
+// tiles per block: as many (16, 8, 4, 2) as still leave FLOWSE_W2D_TPB_BLOCKS = 256 blocks -- ONE per CU, which is all that is
+// resident at a time (A-B-A-B on one box: 256 -> 20.81 k frames/s, 512 -> 20.62 k, 1024 -> 20.38 k) -- so that the prologue is
+// paid once per block and the staging pipeline runs across tile boundaries; needs an even chunk count and
+// must divide the tiles of an image
+static const int g_w2d_tpb_blocks = getenv("FLOWSE_W2D_TPB_BLOCKS") ? atoi(getenv("FLOWSE_W2D_TPB_BLOCKS")) : 256;
 int w2d_tiles_per_block(int B, int H, int W, int Cin, int Cout) {
     int tpb = 1;
     if (((Cin / KC) & 1) == 0) {
         const int64_t blocks1 = ((int64_t)B * H * W / 256) * (Cout / 64);
-        for (int t = 8; t >= 2; t >>= 1)
-            if (((int64_t)H * W / 256) % t == 0 && blocks1 / t >= 512) { tpb = t; break; }
+        for (int t = 16; t >= 2; t >>= 1)
+            if (((int64_t)H * W / 256) % t == 0 && blocks1 / t >= g_w2d_tpb_blocks) { tpb = t; break; }
     }
     return tpb;
 }

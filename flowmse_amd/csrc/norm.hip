@@ -102,7 +102,26 @@ __device__ __forceinline__ void gn_group_stats(const float* __restrict__ p1, int
         if (nch <= 0 || !p) continue;
         const float2* q = reinterpret_cast<const float2*>(p) + (int64_t)b * nblk * Cs + lo;
         const int items = nblk * nch;
-        for (int it = tid; it < items; it += 256) {
+        // four independent requests per round (a thread's items are summed in the same order as one at a time: the loop
+        // was a chain of ~1 us dependent latencies -- 16 rounds for the 1024 strip partials of a 256 x 256 sample)
+        int it = tid;
+        for (; it + 768 < items; it += 1024) {
+            int blk[4];
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = it + 256 * u;
+                blk[u] = k / nch;
+                v[u] = q[(int64_t)blk[u] * Cs + (k - blk[u] * nch)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double n = (double)min(ppb, HW - blk[u] * ppb), m = (double)v[u].x;
+                s1 += n * m;
+                s2 += (double)v[u].y + n * m * m;
+            }
+        }
+        for (; it < items; it += 256) {
             const int blk = it / nch, j = it - blk * nch;
             const float2 v = q[(int64_t)blk * Cs + j];
             const double n = (double)min(ppb, HW - blk * ppb), m = (double)v.x;
