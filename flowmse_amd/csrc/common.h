@@ -349,6 +349,8 @@ bool conv_splitk_is_wino(int B, int H, int W, int Cin, int Cout, int taps);
 // true when the 4-channel input conv runs on the matrix cores (then it also emits fused GroupNorm statistics,
 // H*W/128 partial blocks per sample)
 bool conv_cin4_uses_mfma(int B, int H, int W, int Cout, int taps);
+// statistics blocks per sample the Combine kernel (conv1x1 4 -> C + in-place residual) writes with its output (0: none)
+int conv_cin4_stats_blocks(int B, int H, int W, int Cout);
 
 // direct conv for 4 input channels (input layer, Combine): VALU, HBM-bound
 int launch_conv_cin4(const ConvArgs& a, hipStream_t s);

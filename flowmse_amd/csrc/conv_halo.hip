@@ -419,6 +419,81 @@ __global__ __launch_bounds__(256) void conv_cin4_kernel(ConvArgs a, int Q) {
                 make_float4(o[0] * a.scale, o[1] * a.scale, o[2] * a.scale, o[3] * a.scale));
 }
 
+
+// Combine (conv1x1 4 -> C plus the in-place residual, layerspp.py:55-59) WITH the GroupNorm partial statistics of what it
+// writes: a block owns PB = min(128, H W) consecutive pixels of one sample (its threads = Cout/4 channel quads x 256/(Cout/4)
+// pixel rows walk them), accumulates pivoted (mean, M2) per thread and merges the pixel rows through LDS.  Saves the
+// gn_stats launch that used to re-read the tensor right after this kernel wrote it.
+__global__ __launch_bounds__(256) void conv_cin4_stats_kernel(ConvArgs a, int Q, int PB) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [Cout][4] weights, then [R][Q][8] statistics scratch
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.Cout; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(a.w)[i];
+    __syncthreads();
+    float* red = wl + a.Cout * 4;
+    const int R = 256 / Q;
+    const int HW = a.H * a.W;
+    const int cq = tid % Q, pr = tid / Q;
+    const int64_t m0 = (int64_t)blockIdx.x * PB;
+    const int bs = (int)(m0 / HW);
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + cq * 4);
+    if (a.bias2) {
+        const float4 t = *reinterpret_cast<const float4*>(a.bias2 + (int64_t)bs * a.bias2_stride + cq * 4);
+        bq.x += t.x; bq.y += t.y; bq.z += t.z; bq.w += t.w;
+    }
+    float4 w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = *reinterpret_cast<const float4*>(wl + (cq * 4 + j) * 4);
+    Stat4 st;
+    st.init();
+    for (int p = pr; p < PB; p += R) {
+        const int64_t m = m0 + p;
+        const float4 x = *reinterpret_cast<const float4*>(a.in1 + m * 4);
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.f;
+            acc = fmaf(x.x, w4[j].x, acc);
+            acc = fmaf(x.y, w4[j].y, acc);
+            acc = fmaf(x.z, w4[j].z, acc);
+            acc = fmaf(x.w, w4[j].w, acc);
+            o[j] = acc;
+        }
+        float4 v = make_float4(o[0] + bq.x, o[1] + bq.y, o[2] + bq.z, o[3] + bq.w);
+        const int64_t off = m * a.Cout + cq * 4;
+        if (a.res) {
+            const float4 r = *reinterpret_cast<const float4*>(a.res + off);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
+        *reinterpret_cast<float4*>(a.out + off) = v;
+        st.add(v);
+    }
+    st.finish(red + (pr * Q + cq) * 8);
+    __syncthreads();
+    if (pr == 0) {
+        float acc8[8], nacc = (float)(PB / R);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc8[j] = red[cq * 8 + j];
+        for (int r = 1; r < R; ++r) chan_merge4(nacc, acc8, (float)(PB / R), red + (r * Q + cq) * 8);
+        const int blk = (int)((m0 - (int64_t)bs * HW) / PB);
+        float* dst = a.stats + (((int64_t)bs * a.stats_nblk + blk) * a.Cout + cq * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dst[2 * j] = acc8[j];
+            dst[2 * j + 1] = acc8[4 + j];
+        }
+    }
+}
+
+// statistics blocks per sample of the Combine kernel's fused statistics (0: shape not covered)
+int conv_cin4_stats_blocks(int B, int H, int W, int Cout) {
+    const int HW = H * W, PB = HW < 128 ? HW : 128, Q = Cout / 4;
+    (void)B;
+    if ((Cout & 3) || Q > 256 || (256 % Q) != 0 || (HW % PB) != 0 || (PB % (256 / Q)) != 0) return 0;
+    return HW / PB;
+}
+
 // Matrix-core form of the 4 -> 128 input convolution for full-size images: K = 9 taps x 4 channels = 36 (+4 zero),
 // a lane's A operand is simply the float4 of one neighbouring pixel (taps 2q for lanes 0-31, 2q+1 for lanes 32-63),
 // read straight from global memory; the whole 128 x 40 weight matrix sits in registers.  Block = 128 flat pixels x 128
@@ -486,6 +561,18 @@ int launch_conv_cin4(const ConvArgs& a, hipStream_t s) {
     if (a.C1 != 4 || a.C2 != 0 || (a.Cout & 3) || Q > 256 || (256 % Q) != 0 ||
         (size_t)a.Cout * a.taps * 16 > 64 * 1024) {
         return launch_conv(a, s);      // generic path handles any shape
+    }
+    if (a.stats) {                                       // Combine with fused statistics (fp32, 1x1)
+        const int nblk = conv_cin4_stats_blocks(a.B, a.H, a.W, a.Cout);
+        if (a.taps != 1 || a.out_dt != DT_F32 || nblk == 0 || a.stats_nblk != nblk) {
+            set_error("conv_cin4: fused statistics need a 1x1 fp32 conv on whole statistics blocks (stats_nblk=%d)", a.stats_nblk);
+            return ERR_ARG;
+        }
+        const int PB = a.H * a.W / nblk;
+        const size_t lds_s = (size_t)a.Cout * 16 + (size_t)256 * 8 * sizeof(float);
+        hipLaunchKernelGGL(conv_cin4_stats_kernel, dim3((unsigned)((int64_t)a.B * nblk)), dim3(256), lds_s, s, a, Q, PB);
+        FLOWSE_LAUNCH_CHECK();
+        return OK;
     }
     const int ppb = 256 / Q;
     const int64_t M = (int64_t)a.B * a.H * a.W;

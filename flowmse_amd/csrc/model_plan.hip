@@ -214,6 +214,9 @@ struct Builder {
                                                                                  : conv16_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps))
                              : conv_fused_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps);
         if (cin4 && !out_is_res && C1 == 4 && !has2 && conv_cin4_uses_mfma(Bn, H, Wd, Cout, taps)) st_nblk = H * Wd / 128;
+        // Combine (conv1x1 4 -> C, in place on `res`, fp32): the kernel leaves the statistics of the updated tensor
+        if (cin4 && out_is_res && taps == 1 && C1 == 4 && !has2 && idt == DT_F32 && odt == DT_F32 && Cout >= 16)
+            st_nblk = conv_cin4_stats_blocks(Bn, H, Wd, Cout);
         // conv_ksplit / conv_fused_stats_blocks judge the small-M kernel by the TOTAL channel count; a concat whose parts are
         // not 32-aligned (not in the released net) runs the unsplit flat kernel instead: its statistics geometry applies
         const bool use_smallm = !in16 && !cin4 && M->wsm_offs.count(w) && conv_smallm_ok(Bn, H, Wd, C1, C2, Cout, taps);
@@ -232,6 +235,10 @@ struct Builder {
                                    conv_supports_w2d(Bn, H, Wd, C1, C2, Cout, taps)) ? w2_it->second : -1;
         if (wino2_off >= 0 && st_nblk > 0) st_nblk = H * Wd / 64;
         if (defer || gnf) st_nblk = 0;                   // no output here / the statistics are finished inside the reduction
+        if (out_is_res && o.st_nblk > 0) {               // updated in place: the producer's statistics are stale
+            arena.release(o.st_off);
+            o.st_nblk = 0;
+        }
         if (st_nblk > 0) {
             o.st_nblk = st_nblk;
             o.st_off = arena.alloc((size_t)Bn * st_nblk * Cout * 2 * sizeof(float));
@@ -583,9 +590,8 @@ int build_plan(flowse_model* m, Plan* plan, int B, int F, int T) {
             bd.release(ipyr);
             ipyr = ip2;
             const Module& cb = next();
-            bd.conv("combine_1x1", ipyr, nullptr, cb.w_a, cb.w_a_b, -1, cb.out_ch, 1, &h, 1.f, true, true);
-            bd.drop_stats(h);          // h was updated in place
-            hs.push_back(h);
+            h = bd.conv("combine_1x1", ipyr, nullptr, cb.w_a, cb.w_a_b, -1, cb.out_ch, 1, &h, 1.f, true, true);
+            hs.push_back(h);           // (updated in place; its statistics are the Combine kernel's, or dropped)
         }
     }
     bd.release(ipyr);

@@ -619,7 +619,7 @@ np.savez({dst!r}, **out)
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("switch", ["FLOWSE_NO_WINOGRAD", "FLOWSE_NO_HALO_CONV", "FLOWSE_FORCE_GENERIC_CONV", "FLOWSE_GRAPH",
-                                    "FLOWSE_NO_SMALLM", "FLOWSE_W2D=0"])
+                                    "FLOWSE_NO_SMALLM", "FLOWSE_W2D=0", "FLOWSE_NO_STREAM1X1"])
 def test_library_switches_keep_parity(tmp_path, switch):
     """Every environment switch that selects a different kernel path (read once per process, hence a child process):
     the tiny sampler and the wide (non-power-of-two channel) forward still match the REFERENCE's golden outputs."""
