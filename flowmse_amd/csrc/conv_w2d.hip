@@ -49,8 +49,9 @@ struct W2Tile {
 //     o0 = A + D      o1 = B + 2 E      o2 = C + 4 D      o3 = B + 8 E + F          (A..F = the six partials, per column)
 // Then, wave-private: transposition of its 64 pixels x 32 channels through its own 12 KB slice, bias / per-sample bias /
 // residual / scale, 16-byte stores, GroupNorm partial statistics per (4 x 16 pixel strip, channel).
-template <int CH>
-__device__ __forceinline__ void w2d_out(f32x16 (&acc)[3][2], float* X, int b, int y0, int x0, int n0) {
+// NJ = 1 (32-channel blocks, see the kernel): only waves 0-3 are destinations; the others give and keep the barriers.
+template <int CH, int NJ>
+__device__ __forceinline__ void w2d_out(f32x16 (&acc)[3][NJ], float* X, int b, int y0, int x0, int n0) {
     // The arguments of the output stage are read from the kernel-argument segment HERE (scalar loads, once per tile): kept
     // live across the main loop they were ~20 SGPRs of a kernel that was spilling 58 of them to VGPR lanes
     const ConvArgs* ap = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();   // (C cast: constant -> generic address space)
@@ -62,6 +63,7 @@ __device__ __forceinline__ void w2d_out(f32x16 (&acc)[3][2], float* X, int b, in
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hq = wave & 3;
     const int jD = wave >> 2, gD = wave & 3;             // this wave as a destination
+    const bool dest = jD < NJ;
     const int li = lane & 31, kh = lane >> 5;
     const int W = a.W, Cout = a.Cout;
     const int ch0 = n0 + jD * 32;
@@ -78,14 +80,14 @@ __device__ __forceinline__ void w2d_out(f32x16 (&acc)[3][2], float* X, int b, in
     }
     // residual quads are requested first: in flight during the whole exchange
     float4 rres[8];
-    if (has_res) {
+    if (has_res && dest) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) rres[i] = *reinterpret_cast<const float4*>(resb + roff[i]);
     }
     float* Xd = X + wave * W2_XDEST;
     auto give = [&]() {
 #pragma unroll
-        for (int D = 0; D < 8; ++D) {
+        for (int D = 0; D < 4 * NJ; ++D) {
             const int jd = D >> 2, gd = D & 3;
             float4 v0, v1, v2;
             float* e0 = &v0.x; float* e1 = &v1.x; float* e2 = &v2.x;
@@ -130,10 +132,11 @@ __device__ __forceinline__ void w2d_out(f32x16 (&acc)[3][2], float* X, int b, in
     float SA[2][3][4], SB[2][3][4];
     if (CH == 0) give();
     __syncthreads();
-    take(SA);
+    if (dest) take(SA);
     __syncthreads();
     if (CH == 1) give();
     __syncthreads();
+    if (!dest) return;
     // (bias quads: L2 hits, requested here -- under the second round's reads and sums -- not before the exchange, where
     // eight more live registers spill)
     float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), bq2 = bq;
@@ -199,22 +202,23 @@ __device__ __forceinline__ void w2d_out(f32x16 (&acc)[3][2], float* X, int b, in
     }
 }
 
-template <int GN, int CH>
+template <int GN, int CH, int NJ>
 __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem, int tpb) {
+    constexpr int BN = 32 * NJ;                          // output channels per block
     constexpr int H_LOADS = 6;                           // halo quads per thread and chunk
     float* Hs = smem;                                    // [2][18][W2_HROW]
 
     const int tid = threadIdx.x;
     const int H = a.H, W = a.W, HW = H * W;
     const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
-    const int n_ntiles = a.Cout / 64;
+    const int n_ntiles = a.Cout / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     // a block owns `tpb` consecutive pixel tiles (in walk order) of ONE 64-channel block; the channel blocks of a pixel
     // tile are neighbours in launch order (same XCD, same time: the second one finds the input in L2)
     const int mg = bid / n_ntiles;
     const int nt = bid - mg * n_ntiles;
     const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 4);
-    const int n0 = nt * 64;
+    const int n0 = nt * BN;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Staging map: thread = (pixel slot p = tid >> 3, channel quad tid & 7).  The 18 x 18 halo is walked in SIX rounds of
     // three COLUMNS x 18 rows = 54 pixels (slots 54..63 idle): slot p holds row p % 18 of column p / 18 + 3 q in round q.
@@ -336,7 +340,7 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
     asm volatile("" : "+v"(wvoc[0]), "+v"(wvoc[1]), "+v"(wvoc[2]));     // three registers, not an add per request
     const unsigned wj = 4u * (unsigned)nchunks * 24576u;                 // channel tile 1
 
-    f32x16 acc[3][2];                                    // this wave's three vertical components x two channel tiles
+    f32x16 acc[3][NJ];                                   // this wave's three vertical components x NJ channel tiles
 
     {   // first chunk of the block's first tile: all quads at once (the accumulators are not live yet)
         u32x4 t[H_LOADS];
@@ -404,36 +408,28 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
     // spilled addresses through the in-order vector-memory queue.  Every other instruction rides in an MFMA gap: the ten
     // LDS reads of the next k-block and their horizontal combinations behind component 0, the vertical transform behind
     // component 1, one staged GroupNorm quad (SX) behind component 2.
-#define W2_MF(V, c, K, j)                                                                                            \
-    acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[((c) == 0 && CH == 1) ? 4 : (c)].K, bF[c][j].K, acc[c][j], 0, 0, 0); \
+#define W2_MF(V, c, K)                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                                   \
+        acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[((c) == 0 && CH == 1) ? 4 : (c)].K, bF[c][j].K, acc[c][j], 0, 0, 0); \
     W2_FENCE
-#define W2_PHASE(V, DN, NJ, WB, SX)                                                                                  \
-    W2_MF(V, 0, x, 0) DN[0] = W2_RD(aA0, aA1, 0, NJ); tN[0] = W2_RD(aB0, aB1, 0, NJ); W2_FENCE                       \
-    W2_MF(V, 0, x, 1) DN[1] = W2_RD(aA0, aA1, 1, NJ); tN[1] = W2_RD(aB0, aB1, 1, NJ); W2_FENCE                       \
-    W2_MF(V, 0, y, 0) DN[2] = W2_RD(aA0, aA1, 2, NJ); tN[2] = W2_RD(aB0, aB1, 2, NJ); W2_COMB(DN, tN, 0, 0) W2_FENCE \
-    W2_MF(V, 0, y, 1) DN[3] = W2_RD(aA0, aA1, 3, NJ); tN[0] = W2_RD(aB0, aB1, 3, NJ); W2_COMB(DN, tN, 1, 1) W2_FENCE \
-    W2_MF(V, 0, z, 0) DN[4] = W2_RD(aA0, aA1, 4, NJ); tN[1] = W2_RD(aB0, aB1, 4, NJ); W2_COMB(DN, tN, 2, 2) W2_FENCE \
-    W2_MF(V, 0, z, 1) W2_COMB(DN, tN, 3, 0) W2_FENCE                                                                 \
-    W2_MF(V, 0, w, 0) W2_COMB(DN, tN, 4, 1) W2_FENCE                                                                 \
-    W2_MF(V, 0, w, 1) W2_BLOAD(0, 0, NJ, WB, bF) W2_FENCE                                                            \
-    W2_MF(V, 1, x, 0) W2_BLOAD(0, 1, NJ, WB, bF) W2_FENCE                                                            \
-    W2_MF(V, 1, x, 1) W2_WXA_H(DN, 0) W2_FENCE                                                                       \
-    W2_MF(V, 1, y, 0) W2_WXA_H(DN, 1) W2_FENCE                                                                       \
-    W2_MF(V, 1, y, 1) W2_WXB_H(DN, 0) W2_FENCE                                                                       \
-    W2_MF(V, 1, z, 0) W2_WXB_H(DN, 1) W2_FENCE                                                                       \
-    W2_MF(V, 1, z, 1)                                                                                                \
-    W2_MF(V, 1, w, 0)                                                                                                \
-    W2_MF(V, 1, w, 1) W2_BLOAD(1, 0, NJ, WB, bF) W2_FENCE                                                            \
-    W2_MF(V, 2, x, 0) W2_BLOAD(1, 1, NJ, WB, bF) W2_FENCE                                                            \
-    W2_MF(V, 2, x, 1) SX W2_FENCE                                                                                    \
-    W2_MF(V, 2, y, 0)                                                                                                \
-    W2_MF(V, 2, y, 1)                                                                                                \
-    W2_MF(V, 2, z, 0)                                                                                                \
-    W2_MF(V, 2, z, 1)                                                                                                \
-    W2_MF(V, 2, w, 0)                                                                                                \
-    W2_MF(V, 2, w, 1) W2_BLOAD(2, 0, NJ, WB, bF) W2_BLOAD(2, 1, NJ, WB, bF) W2_FENCE
+#define W2_BL(C, NJB, WB) _Pragma("unroll") for (int j = 0; j < NJ; ++j) W2_BLOAD(C, j, NJB, WB, bF)
+    // twelve (component, k-step) pairs of NJ MFMAs, one filler group behind each
+#define W2_PHASE(V, DN, NJB, WB, SX)                                                                                 \
+    W2_MF(V, 0, x) DN[0] = W2_RD(aA0, aA1, 0, NJB); tN[0] = W2_RD(aB0, aB1, 0, NJB);                                 \
+                   DN[1] = W2_RD(aA0, aA1, 1, NJB); tN[1] = W2_RD(aB0, aB1, 1, NJB); W2_FENCE                        \
+    W2_MF(V, 0, y) DN[2] = W2_RD(aA0, aA1, 2, NJB); tN[2] = W2_RD(aB0, aB1, 2, NJB); W2_COMB(DN, tN, 0, 0) W2_FENCE  \
+    W2_MF(V, 0, z) DN[3] = W2_RD(aA0, aA1, 3, NJB); tN[0] = W2_RD(aB0, aB1, 3, NJB); W2_COMB(DN, tN, 1, 1) W2_FENCE  \
+    W2_MF(V, 0, w) DN[4] = W2_RD(aA0, aA1, 4, NJB); tN[1] = W2_RD(aB0, aB1, 4, NJB); W2_COMB(DN, tN, 2, 2) W2_FENCE  \
+    W2_MF(V, 1, x) W2_BL(0, NJB, WB) W2_COMB(DN, tN, 3, 0) W2_FENCE                                                  \
+    W2_MF(V, 1, y) W2_COMB(DN, tN, 4, 1) W2_WXA_H(DN, 0) W2_FENCE                                                    \
+    W2_MF(V, 1, z) W2_WXA_H(DN, 1) W2_WXB_H(DN, 0) W2_FENCE                                                          \
+    W2_MF(V, 1, w) W2_WXB_H(DN, 1) W2_FENCE                                                                          \
+    W2_MF(V, 2, x) W2_BL(1, NJB, WB) W2_FENCE                                                                        \
+    W2_MF(V, 2, y) SX W2_FENCE                                                                                       \
+    W2_MF(V, 2, z)                                                                                                   \
+    W2_MF(V, 2, w) W2_BL(2, NJB, WB) W2_FENCE
 
-    float4 dA[5], dB[5], tN[3], bF[3][2];
+    float4 dA[5], dB[5], tN[3], bF[3][NJ];
     // operands of a tile's first k-block: requests (LDS rows + weights) and, later, combination + transform.  The block's
     // first tile issues both back to back; at a tile boundary the requests go out inside the output stage (before its
     // stores) and the rest follows it.
@@ -446,7 +442,7 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) W2_BLOAD(c, j, 0, wb, bF)
+            for (int j = 0; j < NJ; ++j) W2_BLOAD(c, j, 0, wb, bF)
     };
     auto start_finish = [&]() {
 #pragma unroll
@@ -486,7 +482,7 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
     for (int slot = 0; slot < nslots; ++slot) {
@@ -513,7 +509,7 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
         W2_PHASE(dB, dA, 0, wbn, { gloadH(stg, sg_c, 0); })
         if (last) {
             const bool more = ti + 1 < tpb;
-            w2d_out<CH>(acc, smem + W2_HBUF, b, cur_y0, cur_x0, n0);
+            w2d_out<CH, NJ>(acc, smem + W2_HBUF, b, cur_y0, cur_x0, n0);
             if (!more) return;
             __syncthreads();                             // buffer 1 (under the exchange region) is written again in the next tile
             // (the operands phase 3 fetched for the next tile were not kept across the output stage: 36 registers.  Requesting
@@ -529,7 +525,7 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
             ++ti;
@@ -548,15 +544,20 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
 #undef W2_WXA_H
 #undef W2_WXB_H
 #undef W2_MF
+#undef W2_BL
 #undef W2_PHASE
 }
 
-template <int GN>
+// NJ = 2: 64 output channels per block (two 32-channel tiles per wave).  NJ = 1: 32 channels per block -- twice the blocks
+// for launches that would leave CUs idle (the 32 x 32 level at batch 8: 128 blocks of 64 channels, 256 of 32): every staged
+// halo element and every transformed operand feeds half the MFMAs, but all 256 CUs work with two waves per SIMD, where the
+// 1-D kernel's 64-channel form runs one 4-wave block per CU.
+template <int GN, int NJ>
 __global__ __launch_bounds__(512, 2) void conv3x3_w2d_kernel(ConvArgs a, int tpb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // waves 0..3: vertical half 0; waves 4..7: half 1.  Both bodies execute the same barriers.
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) conv3x3_w2d_body<GN, 1>(a, smem, tpb);
-    else conv3x3_w2d_body<GN, 0>(a, smem, tpb);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) conv3x3_w2d_body<GN, 1, NJ>(a, smem, tpb);
+    else conv3x3_w2d_body<GN, 0, NJ>(a, smem, tpb);
 }
 
 // [Cout][9][Cin] -> fragment order [Cout/32][h 0..3][Cin/32][component 0..5][k-block j][lane][4]; stored vertical component
@@ -607,13 +608,17 @@ int launch_w2d_weights(const float* w_packed, int Cout, int Cin, float* out, hip
 
 // tiles per block: as many (16, 8, 4, 2) as still leave FLOWSE_W2D_TPB_BLOCKS = 256 blocks -- ONE per CU, which is all that is
 // resident at a time (A-B-A-B on one box: 256 -> 20.81 k frames/s, 512 -> 20.62 k, 1024 -> 20.38 k) -- so that the prologue is
-// paid once per block and the staging pipeline runs across tile boundaries; needs an even chunk count and
-// must divide the tiles of an image
+// paid once per block and the staging pipeline runs across tile boundaries; needs an even chunk count and must divide the
+// tiles of an image
 static const int g_w2d_tpb_blocks = getenv("FLOWSE_W2D_TPB_BLOCKS") ? atoi(getenv("FLOWSE_W2D_TPB_BLOCKS")) : 256;
+// channel tiles per block: 2 (64 channels) when that gives every CU two blocks' worth of work, else 1 (32 channels)
+int w2d_channel_tiles(int B, int H, int W, int Cout) {
+    return ((int64_t)B * H * W / 256) * (Cout / 64) >= 512 ? 2 : 1;
+}
 int w2d_tiles_per_block(int B, int H, int W, int Cin, int Cout) {
     int tpb = 1;
     if (((Cin / KC) & 1) == 0) {
-        const int64_t blocks1 = ((int64_t)B * H * W / 256) * (Cout / 64);
+        const int64_t blocks1 = ((int64_t)B * H * W / 256) * (Cout / (32 * w2d_channel_tiles(B, H, W, Cout)));
         for (int t = 16; t >= 2; t >>= 1)
             if (((int64_t)H * W / 256) % t == 0 && blocks1 / t >= g_w2d_tpb_blocks) { tpb = t; break; }
     }
@@ -622,16 +627,21 @@ int w2d_tiles_per_block(int B, int H, int W, int Cin, int Cout) {
 
 int launch_w2d(const ConvArgs& a, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
+    const int nj = w2d_channel_tiles(a.B, a.H, a.W, a.Cout);
     const int tpb = w2d_tiles_per_block(a.B, a.H, a.W, a.C1 + a.C2, a.Cout);
-    const int grid = (int)(M / 256 / tpb) * (a.Cout / 64);
+    const int grid = (int)(M / 256 / tpb) * (a.Cout / (32 * nj));
     const size_t lds = (W2_HBUF + 8 * W2_XDEST) * sizeof(float);       // halo buffer 0 + the exchange region (> two halo buffers)
     const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;
-#define FLOWSE_LW2D(G)                                                                                       \
+#define FLOWSE_LW2D(G, J)                                                                                    \
     {                                                                                                        \
-        if (const int rc = allow_lds<&conv3x3_w2d_kernel<G>>(lds)) return rc;                                \
-        hipLaunchKernelGGL((conv3x3_w2d_kernel<G>), dim3(grid), dim3(512), lds, s, a, tpb);                   \
+        if (const int rc = allow_lds<&conv3x3_w2d_kernel<G, J>>(lds)) return rc;                             \
+        hipLaunchKernelGGL((conv3x3_w2d_kernel<G, J>), dim3(grid), dim3(512), lds, s, a, tpb);                \
     }
-    if (gn == 2) FLOWSE_LW2D(2) else if (gn == 1) FLOWSE_LW2D(1) else FLOWSE_LW2D(0)
+    if (nj == 2) {
+        if (gn == 2) FLOWSE_LW2D(2, 2) else if (gn == 1) FLOWSE_LW2D(1, 2) else FLOWSE_LW2D(0, 2)
+    } else {
+        if (gn == 2) FLOWSE_LW2D(2, 1) else if (gn == 1) FLOWSE_LW2D(1, 1) else FLOWSE_LW2D(0, 1)
+    }
 #undef FLOWSE_LW2D
     FLOWSE_LAUNCH_CHECK();
     return OK;

@@ -237,6 +237,8 @@ W2D_CASES = [
     (2, 256, 128, 64, 32, 128, True, False, 1.0, True),          # concat 64 + 32: odd chunk count (3), tiles per block 1
     (1, 256, 256, 128, 128, 256, True, True, 1.0, False),        # concat, 8 chunks, GroupNorm without SiLU, Cout 256
     (4, 64, 192, 32, 0, 64, False, False, 1.0, True),            # one chunk per tile, W = 12 tiles (row-major walk)
+    (8, 32, 32, 256, 0, 256, True, True, 0.70710678, True),      # 32 tiles: the 32-channel-block form (256 blocks), Cout 256
+    (8, 256, 256, 128, 0, 128, False, True, 1.0, True),          # the dominant launch: 16 tiles per block
 ]
 
 
