@@ -569,7 +569,7 @@ def main():
                 form = "F(4,3)" if os.environ.get("FLOWSE_W2D", "1")[:1] == "0" else "F(4,3)xF(2,3)"
             kname = ("flowse::conv3x3_w2d_kernel<2> (fp32 two-dimensional Winograd F(4,3) x F(2,3) implicit-GEMM 3x3 conv, 16x16 "
                      "pixel x 64 channel block of 8 waves, LDS halo, fused GroupNorm+SiLU input, weights streamed from L2 in MFMA "
-                     "fragment order) on launches of >= 512 such blocks, flowse::conv3x3_f43_kernel<2, false, *> (1-D F(4,3)) on "
+                     "fragment order; 32-channel blocks on launches of 128-255 such blocks), flowse::conv3x3_f43_kernel<2, false, *> (1-D F(4,3)) on "
                      "the smaller ones" if form == "F(4,3)xF(2,3)" else
                      "flowse::conv3x3_f43_kernel<2, false, 2>" +
                      f" (fp32 {form}-Winograd implicit-GEMM 3x3 conv, 8x16 pixel x 128 channel block, LDS halo, fused "

@@ -128,16 +128,16 @@ bool conv_supports_wino(int B, int H, int W, int C1, int C2, int Cout, int taps)
 
 // The two-dimensional form: whole-K launches on images that give every CU at least two blocks of 16 x 16 pixels x 64
 // channels, or one of 32 channels (below that the 1-D kernel's K slices fill the chip better).
-static const int g_w2d_min_blocks = getenv("FLOWSE_W2D_MIN_BLOCKS") ? atoi(getenv("FLOWSE_W2D_MIN_BLOCKS")) : 512;
+static const int g_w2d_min_blocks = getenv("FLOWSE_W2D_MIN_BLOCKS") ? atoi(getenv("FLOWSE_W2D_MIN_BLOCKS")) : 128;
 bool conv_w2d_shape_ok(int B, int H, int W, int C1, int C2, int Cout, int taps) {
     if (g_no_wino_policy || taps != 9 || (H & 15) || (W & 15) || (C1 % KC) || (C2 % KC) || (Cout % 64) || B < 1) return false;
     const int64_t cmax = C1 > C2 ? C1 : C2;
     return (int64_t)Cout * 24 * (C1 + C2) * 4 < (1LL << 31) && ((int64_t)H * W + 2 * W + 2) * cmax * 4 < (1LL << 31);
 }
 bool conv_supports_w2d(int B, int H, int W, int C1, int C2, int Cout, int taps) {
-    // >= 512 blocks of 64 channels, or -- with 32-channel blocks (conv3x3_w2d_kernel<GN, 1>) -- at least one block per CU
+    // at least one block per CU: of 64 channels, or -- 128..255 such blocks -- of 32 channels (conv3x3_w2d_kernel<GN, 1>)
     const int64_t b64 = ((int64_t)B * H * W / 256) * (Cout / 64);
-    return conv_w2d_shape_ok(B, H, W, C1, C2, Cout, taps) && (b64 >= g_w2d_min_blocks || (g_w2d_min_blocks == 512 && 2 * b64 >= 256));
+    return conv_w2d_shape_ok(B, H, W, C1, C2, Cout, taps) && b64 >= g_w2d_min_blocks;
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {

@@ -611,18 +611,28 @@ int launch_w2d_weights(const float* w_packed, int Cout, int Cin, float* out, hip
 // paid once per block and the staging pipeline runs across tile boundaries; needs an even chunk count and must divide the
 // tiles of an image
 static const int g_w2d_tpb_blocks = getenv("FLOWSE_W2D_TPB_BLOCKS") ? atoi(getenv("FLOWSE_W2D_TPB_BLOCKS")) : 256;
-// channel tiles per block: 2 (64 channels) when that gives every CU two blocks' worth of work, else 1 (32 channels)
+// channel tiles per block: 2 (64 channels) when that gives every CU a block, else 1 (32 channels: twice the blocks).  Measured
+// at 256 / 384 blocks of 64 channels: 76 vs 91 us and 144 vs 172 us for the 64-channel form (profiles/r05_w2d_probes.md)
+static const int g_w2d_nj2_blocks = getenv("FLOWSE_W2D_NJ2_BLOCKS") ? atoi(getenv("FLOWSE_W2D_NJ2_BLOCKS")) : 256;
 int w2d_channel_tiles(int B, int H, int W, int Cout) {
-    return ((int64_t)B * H * W / 256) * (Cout / 64) >= 512 ? 2 : 1;
+    return ((int64_t)B * H * W / 256) * (Cout / 64) >= g_w2d_nj2_blocks ? 2 : 1;
 }
 int w2d_tiles_per_block(int B, int H, int W, int Cin, int Cout) {
-    int tpb = 1;
-    if (((Cin / KC) & 1) == 0) {
-        const int64_t blocks1 = ((int64_t)B * H * W / 256) * (Cout / (32 * w2d_channel_tiles(B, H, W, Cout)));
-        for (int t = 16; t >= 2; t >>= 1)
-            if (((int64_t)H * W / 256) % t == 0 && blocks1 / t >= g_w2d_tpb_blocks) { tpb = t; break; }
+    if (((Cin / KC) & 1) != 0) return 1;
+    const int64_t blocks1 = ((int64_t)B * H * W / 256) * (Cout / (32 * w2d_channel_tiles(B, H, W, Cout)));
+    // One block per CU is resident at a time, so the blocks run in rounds of 256: the largest t whose LAST round is still
+    // (nearly) full -- 384 blocks would leave half the chip idle for a whole block (the ragged widths of config[3]: 19.6 k vs
+    // 18.0 k frames/s on one rank's share) -- else the best-balanced t.
+    int best = 1;
+    double best_eff = 0.0;
+    for (int t = 16; t >= 1; t >>= 1) {
+        if (((int64_t)H * W / 256) % t != 0 || blocks1 / t < g_w2d_tpb_blocks) continue;
+        const int64_t nb = blocks1 / t;
+        const double eff = (double)nb / (256.0 * (double)((nb + 255) / 256));
+        if (eff >= 0.94) return t;
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = t; }
     }
-    return tpb;
+    return best;
 }
 
 int launch_w2d(const ConvArgs& a, hipStream_t s) {

@@ -247,8 +247,8 @@ int64_t flowse_op_conv3x3_f43_scratch_floats(int B, int H, int W, int C, int Cou
 /* The same contract in the TWO-dimensional Winograd form F(4,3) (vertical) x F(2,3) (horizontal): 24 multiplies per
  * 4 x 2 output patch instead of 72 (one third of the direct-convolution FLOPs on the matrix cores; fp32 error ~1.5x the
  * 1-D form's).  Covers H % 16 == 0, W % 16 == 0, channel counts multiples of 32, Cout % 64 == 0; other shapes:
- * FLOWSE_ERR_SHAPE.  The model handle uses it for launches of at least 512 blocks of 16 x 16 pixels x 64 channels
- * unless FLOWSE_W2D=0. */
+ * FLOWSE_ERR_SHAPE.  The model handle uses it for launches of at least 128 blocks of 16 x 16 pixels x 64 channels (below
+ * 256 of them with 32-channel blocks, so that every CU gets one) unless FLOWSE_W2D=0. */
 int flowse_op_conv3x3_w2d(const float* in1, int C1, const float* in2, int C2, const float* gamma, const float* beta,
                           float eps, int silu, const float* w, const float* bias, const float* bias2,
                           int bias2_stride, const float* res, float* out, int B, int H, int W, int Cout, float scale,

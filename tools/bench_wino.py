@@ -28,6 +28,10 @@ SHAPES = [  # B, H, W, C1, C2, Cout   (launches per NFE at [8,1,256,256])
     (8, 32, 32, 256, 0, 256),
     (1, 256, 256, 128, 0, 128),
     (1, 128, 128, 128, 0, 128),
+    (8, 64, 48, 256, 0, 256),        # 384 blocks of 64 channels (T = 192 at the 64-row level)
+    (8, 64, 32, 256, 0, 256),        # 256
+    (8, 32, 48, 256, 0, 256),        # 192 (T = 384 at the 32-row level)
+    (8, 128, 48, 128, 0, 128),       # 384 (T = 96 ... the 128-row level of short utterances)
 ]
 
 
