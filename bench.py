@@ -560,8 +560,11 @@ def main():
             if tfiles and (B, T, NS, args.precision) == (8, 256, 5, "fp32"):   # PMC passes were taken on this workload
                 tj = json.load(open(tfiles[-1]))
                 k = tj.get("dominant_kernel")
-                if k:
+                if tj.get("dominant_set"):                  # launch-weighted over every instantiation bracketed here
+                    traffic = tj["dominant_set"]["hbm_bytes_per_launch"]
+                elif k:
                     traffic = tj["kernels"][k]["hbm_bytes_per_launch"]
+                if traffic is not None:
                     traffic_src = (f"profiles/{os.path.basename(tfiles[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                    "own passes, 2*FETCH_SIZE + WRITE_SIZE)")
             form = None
