@@ -424,47 +424,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         FLOWSE_PC_WLOAD(0, wc0, wc1, 0) FLOWSE_PC_WLOAD(1, wc0, wc1, 1) FLOWSE_PC_WLOAD(2, wc0, wc1, 2)
         __syncthreads();                                   // (X 0)
         FLOWSE_PC_LOADA(xa, 0, 0, 0)
-        // One folded-shortcut chunk (ordinal S of the tile, ring entry R): its own chunk barrier, one step.  The refill of entry R
-        // comes from the shortcut step three ahead (the last one again past the end: never used).
-#define FLOWSE_PC_SCHUNK(R, S)                                                                                       \
-    {                                                                                                                \
-        const int hnext = hoff == (PC_NHBUF - 1) * PC_HBUF_X ? 0 : hoff + PC_HBUF_X;                                 \
-        __syncthreads();                                   /* (X) */                                                \
-        PC_TS_ADD(1)                                                                                                 \
-        chunk_off(nb_cur, nchunks + min((S) + 3, ns - 1), wn0, wn1);                                                 \
-        FLOWSE_PC_SSTEP(R)                                                                                           \
-        PC_TS_ADD(0)                                                                                                 \
-        hoff = hnext;                                                                                                \
-    }
-        for (int gc = 0; gc < Ctot;) {
-            const bool tile_end = cit == nchunks - 1;      // the tile's last NINE-TAP chunk
-            {
-                const int hnext = hoff == (PC_NHBUF - 1) * PC_HBUF_X ? 0 : hoff + PC_HBUF_X;
-                if (gc > 0) __syncthreads();               // (X gc) the halos of chunks gc and gc + 1 are in LDS; the producers may
-                PC_TS_ADD(1)                               //        overwrite the buffer of chunk gc - 1.   1: chunk barrier
+        for (int gc = 0; gc < Ctot; ++gc) {
+            const bool tile_end = cit == nct - 1;
+            const int hnext = hoff == (PC_NHBUF - 1) * PC_HBUF_X ? 0 : hoff + PC_HBUF_X;
+            if (gc > 0) __syncthreads();                   // (X gc) the halos of chunks gc and gc + 1 are in LDS; the producers may
+            PC_TS_ADD(1)                                   //        overwrite the buffer of chunk gc - 1.   1: chunk barrier
+            if (cit < nchunks) {
                 chunk_off(nb_cur, cit, wc0, wc1);
-                if (!tile_end || ns) chunk_off(nb_cur, cit + 1, wn0, wn1);     // (cit + 1 = nchunks: the shortcut's first steps)
+                if (!tile_end) chunk_off(nb_cur, cit + 1, wn0, wn1);
                 else chunk_off(nb_next, 0, wn0, wn1);
                 FLOWSE_PC_STEP(0) FLOWSE_PC_STEP(1) FLOWSE_PC_STEP(2) FLOWSE_PC_STEP(3) FLOWSE_PC_STEP(4) FLOWSE_PC_STEP(5)
                 FLOWSE_PC_STEP(6) FLOWSE_PC_RESLOAD(0) FLOWSE_PC_STEP(7) FLOWSE_PC_RESLOAD(1) FLOWSE_PC_STEP(8) FLOWSE_PC_RESLOAD(2)
-                PC_TS_ADD(0)                               // 0: fragments + MFMA issue
-                hoff = hnext;
             }
+            const int r3 = cit >= nchunks ? (cit - nchunks) % 3 : -1;
+            if (cit >= nchunks) chunk_off(nb_cur, min(cit + 3, nct - 1), wn0, wn1);
+            if (r3 == 0) FLOWSE_PC_SSTEP(0)
+            if (r3 == 1) FLOWSE_PC_SSTEP(1)
+            if (r3 == 2) FLOWSE_PC_SSTEP(2)
+            PC_TS_ADD(0)                                   // 0: fragments + MFMA issue
             ++cit;
-            ++gc;
-            if (tile_end) {
-                if (ns) {                                  // the folded shortcut: ns one-step chunks, ring entries 0, 1, 2, 0, ...
-                    for (int sq = 0; sq < ns; sq += 3) {
-                        FLOWSE_PC_SCHUNK(0, sq)
-                        if (sq + 1 < ns) {
-                            FLOWSE_PC_SCHUNK(1, sq + 1)
-                            if (sq + 2 < ns) FLOWSE_PC_SCHUNK(2, sq + 2)
-                        }
-                    }
-                    gc += ns;
-                }
-                // the tile is complete: output stage (its block barrier (S) is matched by the producers), next tile
-                const PcItem p = pit;
+            if (tile_end) {                                // the tile is complete: output stage (its block barrier (S) is matched
+                const PcItem p = pit;                      // by the producers), next tile
                 if (has_res) pc16_out_wide<T16, true>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x, wb, po);
                 else pc16_out_wide<T16, false>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x, wb, po);
                 zero_acc();
@@ -479,10 +459,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
                     chunk_off(nb_cur, 0, wc0, wc1);        //  steps 0-2)
                     FLOWSE_PC_WLOAD(0, wc0, wc1, 0) FLOWSE_PC_WLOAD(1, wc0, wc1, 1) FLOWSE_PC_WLOAD(2, wc0, wc1, 2)
                 }
-                FLOWSE_PC_LOADA(xa, hoff, 0, 0)            // (in LDS since the barrier of the finished chunk; a stale read after the last tile is never used)
+                FLOWSE_PC_LOADA(xa, hnext, 0, 0)           // (in LDS since the barrier of the finished chunk; a stale read after the last tile is never used)
             }
+            hoff = hnext;
         }
-#undef FLOWSE_PC_SCHUNK
         PC_TS_EXIT
         if (wave == 0) { PC_TS_FLUSH(0) }                  // slots 0-7 of the block
 #undef FLOWSE_PC_RESLOAD

@@ -260,6 +260,15 @@ struct ConvArgs {
     int terms = 0;
     int wq_f16 = 0;     // 1: the planes hold IEEE half instead of bf16 (terms must be 1; BASELINE config 5)
     const void* wfrag = nullptr;   // the same 3x3 weights in MFMA fragment order (launch_pc16_weights): conv3x3_pc16_kernel's B operand
+    // The 1x1 shortcut of a ResnetBlock folded into its second 3x3 (conv3x3_pc16_kernel only): out = (conv3x3(act(GN(in)))
+    // + bias + conv1x1(cat[sc1, sc2]; wfrag_sc) + bias_x) * scale -- layerspp.py:265-274 in ONE launch.  The shortcut's
+    // SC1 + SC2 raw input channels (16-bit storage, same B / H / W, no GroupNorm) are extra K steps of every tile after its
+    // nine-tap chunks; wfrag_sc = the 1x1 weights [Cout][1][SC1 + SC2] in fragment order (launch_pc16_weights, taps = 1).
+    // Excludes `res`.
+    const void* sc1 = nullptr;
+    const void* sc2 = nullptr;
+    int SC1 = 0, SC2 = 0;
+    const void* wfrag_sc = nullptr;
     // optional F(4,3) Winograd weights of a 3x3 conv in MFMA fragment order (launch_f43_weights): when set and the
     // shape qualifies (conv_supports_wino) the fp32 3x3 runs the Winograd kernel (18 transformed taps per channel pair)
     const float* wino = nullptr;

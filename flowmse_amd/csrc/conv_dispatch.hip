@@ -150,6 +150,14 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool with_reduce) {
         set_error("conv: too many pixels for 32-bit pixel indices");
         return ERR_SHAPE;
     }
+    if (a.sc1 || a.sc2 || a.wfrag_sc) {               // folded 1x1 shortcut: the producer / consumer kernel only
+        if (a.in_dt == DT_F32 || a.ksplit > 1 || a.out_dt != a.in_dt || !a.wfrag ||
+            !conv16_uses_pc(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
+            set_error("conv: a folded shortcut needs a launch of conv3x3_pc16_kernel (16-bit storage, 16 x 16-pixel tiles)");
+            return ERR_ARG;
+        }
+        return launch_pc16(a, s);
+    }
     if (a.in_dt != DT_F32) {                          // activations stored as bf16 / half
         if (a.ksplit <= 1 && !a.partial && !a.bias2 && !a.stats && a.out_dt == DT_F32 &&
             conv_supports_head4(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps))

@@ -1012,6 +1012,68 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
     return launch_convert(o16, dt, out, DT_F32, M * Cout, s);
 }
 
+// Tail of ResnetBlockBigGANpp in 16-bit storage as ONE launch of the producer / consumer kernel:
+//   out = (conv3x3(act(GroupNorm(h)); w1) + b1 + conv1x1(cat[x1, x2]; w2) + b2) * scale       (layerspp.py:265-274)
+// with the shortcut as extra K steps (ConvArgs::sc1).  fp32 tensors at the boundary as in flowse_op_conv2d_16.
+int flowse_op_resblock_tail_16(const float* h, int C, const float* gn_mean, const float* gn_scale, const float* gn_beta,
+                               int silu, const float* w1, const float* b1, const float* x1, int XC1, const float* x2,
+                               int XC2, const float* w2, const float* b2, float* out, int B, int H, int W, int Cout,
+                               float scale, int dt, void* scratch, int64_t scratch_bytes, void* stream) {
+    if (!h || !w1 || !x1 || !w2 || !out || !scratch || (dt != DT_BF16 && dt != DT_F16)) {
+        set_error("flowse_op_resblock_tail_16: bad argument");
+        return ERR_ARG;
+    }
+    if (!x2) XC2 = 0;
+    if (!conv16_uses_pc(B, H, W, C, 0, Cout, 9)) {
+        set_error("flowse_op_resblock_tail_16: only shapes conv3x3_pc16_kernel takes (H, W multiples of 16, C %% 32 == 0, "
+                  "Cout %% 128 == 0, >= 64 tile x channel-block items)");
+        return ERR_SHAPE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t M = (int64_t)B * H * W, XC = (int64_t)XC1 + XC2;
+    const int64_t nw1 = ((int64_t)Cout * 9 * C + 3) & ~(int64_t)3, nw2 = ((int64_t)Cout * XC + 3) & ~(int64_t)3;
+    auto up = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
+    const int64_t need = up(2 * M * C) + up(2 * M * XC1) + up(2 * M * XC2) + 2 * up(2 * nw1) + 2 * up(2 * nw2) + up(2 * M * Cout);
+    if (scratch_bytes < need) {
+        set_error("flowse_op_resblock_tail_16: scratch needs %lld bytes", (long long)need);
+        return ERR_ARG;
+    }
+    char* p = static_cast<char*>(scratch);
+    auto take = [&](int64_t bytes) { char* q = p; p += (bytes + 255) & ~(int64_t)255; return q; };
+    void* h16 = take(2 * M * C);
+    void* a1 = take(2 * M * XC1);
+    void* a2 = XC2 ? take(2 * M * XC2) : nullptr;
+    void* wq1 = take(2 * nw1);
+    void* wf1 = take(2 * nw1);
+    void* wq2 = take(2 * nw2);
+    void* wf2 = take(2 * nw2);
+    void* o16 = take(2 * M * Cout);
+    int rc = launch_convert(h, DT_F32, h16, dt, M * C, s);
+    if (rc == OK) rc = launch_convert(x1, DT_F32, a1, dt, M * XC1, s);
+    if (rc == OK && XC2) rc = launch_convert(x2, DT_F32, a2, dt, M * XC2, s);
+    if (rc == OK) rc = launch_convert(w1, DT_F32, wq1, dt, nw1, s);
+    if (rc == OK) rc = launch_convert(w2, DT_F32, wq2, dt, nw2, s);
+    if (rc == OK) rc = launch_pc16_weights(wq1, Cout, C, wf1, s, 9);
+    if (rc == OK) rc = launch_pc16_weights(wq2, Cout, (int)XC, wf2, s, 1);
+    if (rc != OK) return rc;
+    ConvArgs c;
+    c.in1 = static_cast<const float*>(h16); c.in2 = nullptr; c.C1 = C; c.C2 = 0;
+    c.w = w1; c.bias = b1; c.bias_x = b2; c.bias2 = nullptr; c.bias2_stride = 0; c.res = nullptr;
+    c.out = static_cast<float*>(o16);
+    c.B = B; c.H = H; c.W = W; c.Cout = Cout; c.taps = 9; c.scale = scale;
+    c.wq = wq1; c.terms = 1; c.wq_f16 = dt == DT_F16 ? 1 : 0;
+    c.wfrag = wf1;
+    c.sc1 = a1; c.SC1 = XC1; c.sc2 = a2; c.SC2 = XC2; c.wfrag_sc = wf2;
+    c.in_dt = dt; c.out_dt = dt;
+    if (gn_mean) {
+        c.gn = GnParams{gn_mean, gn_scale, gn_beta};
+        c.gn_silu = silu;
+    }
+    rc = launch_conv(c, s);
+    if (rc != OK) return rc;
+    return launch_convert(o16, dt, out, DT_F32, M * Cout, s);
+}
+
 int flowse_op_fir_up(const float* in, float* out, int B, int H, int W, int C, void* stream) {
     GnParams p{nullptr, nullptr, nullptr};
     return launch_fir_up(in, B, H, W, C, p, 0, nullptr, out, static_cast<hipStream_t>(stream));

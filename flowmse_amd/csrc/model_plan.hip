@@ -25,6 +25,12 @@ struct SkPartial {
     int64_t bias = -1;
     bool valid = false;
 };
+// The 1x1 shortcut Conv_2(x) of a ResnetBlock folded into Conv_1's launch (ConvArgs::sc1, conv3x3_pc16_kernel only)
+struct ScFold {
+    const Tn* s1 = nullptr;
+    const Tn* s2 = nullptr;             // second part of a concat input, or null
+    int64_t w = -1, bias = -1;          // packed offsets of Conv_2's weight / bias
+};
 // Request to fuse the GroupNorm that consumes a split-K conv's output into its reduction launch
 // (launch_splitk_reduce_gn).  apply: the conv returns act(GroupNorm(out)); else it returns out and fills `g`.
 struct GnFuse {
@@ -182,7 +188,8 @@ struct Builder {
     Tn conv(const std::string& label, const Tn& a, const Tn* b2, int64_t w, int64_t bias, int dense_row0, int Cout,
             int taps, const Tn* res, float scale, bool out_is_res = false, bool cin4 = false,
             const GnBuf* gin = nullptr, bool gin_silu = false, int64_t wq_off = -1, int out_dt = -1,
-            SkPartial* defer = nullptr, const SkPartial* extra = nullptr, GnFuse* gnf = nullptr) {
+            SkPartial* defer = nullptr, const SkPartial* extra = nullptr, GnFuse* gnf = nullptr,
+            const ScFold* fold = nullptr) {
         flowse_model* M = m;
         const int C1 = a.C, C2 = b2 ? b2->C : 0, H = a.H, Wd = a.W, Bn = B;
         {   // a deferred reduction leaves no output tensor: decide before anything is allocated
@@ -256,8 +263,18 @@ struct Builder {
         const size_t table_off = M_table_off;     // by value: the Builder dies before the plan runs
         const bool has_extra = extra != nullptr && extra->valid;
         const SkPartial xp = has_extra ? *extra : SkPartial();
+        const bool has_fold = fold != nullptr;
+        const size_t f1_off = has_fold ? fold->s1->off : 0, f2_off = has_fold && fold->s2 ? fold->s2->off : 0;
+        const int FC1 = has_fold ? fold->s1->C : 0, FC2 = has_fold && fold->s2 ? fold->s2->C : 0;
+        const int64_t fold_w = has_fold ? fold->w : -1, fold_b = has_fold ? fold->bias : -1;
+        if (has_fold && (res || extra || ks != 1 || !in16 || taps != 9 || fold->s1->H != H || fold->s1->W != Wd ||
+                         fold->s1->dt != idt || !M->frag_offs.count(w) || !M->frag_offs.count(fold_w))) {
+            set_error("internal: shortcut fold requested for a conv that cannot take it (%s)", label.c_str());
+            failed = true;
+        }
         const std::string full_label = label + "@" + std::to_string(H) + "x" + std::to_string(Wd) + ":" +
-                                       std::to_string(C1 + C2) + ">" + std::to_string(Cout);
+                                       std::to_string(C1 + C2) + (has_fold ? "+" + std::to_string(FC1 + FC2) : std::string()) +
+                                       ">" + std::to_string(Cout);
         auto make_args = [=]() {
             ConvArgs c;
             c.in1 = M->A(a_off);
@@ -286,6 +303,14 @@ struct Builder {
                 c.gn = GnParams{M->A(gbuf.mean), M->A(gbuf.scale), M->W(gbuf.beta)};
                 c.gn_silu = gin_silu ? 1 : 0;
             }
+            if (has_fold) {                               // Conv_2(x) as extra K steps of this launch
+                c.sc1 = M->A(f1_off);
+                c.SC1 = FC1;
+                c.sc2 = FC2 ? M->A(f2_off) : nullptr;
+                c.SC2 = FC2;
+                c.wfrag_sc = M->d_wfrag + fold_w;
+                c.bias_x = fold_b >= 0 ? M->W(fold_b) : nullptr;
+            }
             c.in_dt = idt;
             c.out_dt = odt;
             if (in16) {                                   // [Cout][taps][Cin] in the storage type: same offsets as d_w
@@ -307,9 +332,10 @@ struct Builder {
             if (use_stream) c.wsm = M->d_wsm + w;
             return c;
         };
-        const double flops = 2.0 * Bn * H * Wd * (double)Cout * taps * (C1 + C2);
+        const double flops = 2.0 * Bn * H * Wd * (double)Cout * (taps * (C1 + C2) + (FC1 + FC2));
         const double out_bytes = (double)dt_size(odt) * Bn * H * Wd * Cout * (hasres ? 2 : 1);
-        const double in_bytes = (double)dt_size(idt) * ((double)Bn * H * Wd * (C1 + C2) + (double)Cout * taps * (C1 + C2));
+        const double in_bytes = (double)dt_size(idt) * ((double)Bn * H * Wd * (C1 + C2 + FC1 + FC2) +
+                                                        (double)Cout * (taps * (C1 + C2) + (FC1 + FC2)));
         const double part_bytes = 4.0 * ks * (double)Bn * H * Wd * Cout;
         op(full_label, [=](hipStream_t s) {
             const ConvArgs c = make_args();
@@ -421,8 +447,17 @@ struct Builder {
         SkPartial sp;
         const bool merge_sc = mod.shortcut && sk_two_pass(x1.dt, Ho, Wo, mod.out_ch, mod.out_ch, 9) &&
                               sk_two_pass(x1.dt, Ho, Wo, mod.in_ch, mod.out_ch, 1);
+        // 16-bit storage, Conv_1 on the producer / consumer kernel: the shortcut Conv_2(x) runs as extra K steps of Conv_1's
+        // launch (ConvArgs::sc1) -- no launch, no round trip of its output through HBM, one read of x less
+        const int xc2 = (!mod.up && !mod.down && x2) ? x2->C : 0;
+        const bool fold_sc = mod.shortcut && m->act_dt != DT_F32 && !merge_sc && !getenv("FLOWSE_NO_SCFOLD") &&
+                             m->frag_offs.count(mod.w_c1) && m->frag_offs.count(mod.w_c2) &&
+                             conv16_uses_pc(B, Ho, Wo, mod.out_ch, 0, mod.out_ch, 9) &&
+                             fusable_shape(m->act_dt, Ho, Wo, mod.out_ch, 0) && (x1.C % 32) == 0 && (xc2 % 32) == 0 &&
+                             x1.C + xc2 >= 96 && x1.dt == m->act_dt;
+        Tn xr;
         if (!mod.up && !mod.down) {
-            if (mod.shortcut) {
+            if (mod.shortcut && !fold_sc) {
                 xs = conv("conv2_1x1", x1, x2, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f, false, false, nullptr,
                           false, -1, -1, merge_sc ? &sp : nullptr);
             }
@@ -440,16 +475,16 @@ struct Builder {
             }
         } else {
             GnBuf g0 = gn(x1, x2, mod.w_gn0_g, mod.w_gn0_b);
-            Tn xr;
             Tn hr = fir(x1, mod.up, &g0, true, nullptr, false, &xr);      // act(GN(x)) and x resampled in one pass
             gn_release(g0);
             // the shortcut Conv_2(x) (layerspp.py:268-270)
-            xs = conv("conv2_1x1", xr, nullptr, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f, false, false, nullptr,
-                      false, -1, -1, merge_sc ? &sp : nullptr);
+            if (!fold_sc)
+                xs = conv("conv2_1x1", xr, nullptr, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f, false, false, nullptr,
+                          false, -1, -1, merge_sc ? &sp : nullptr);
             h1 = conv("conv0_3x3", hr, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f, false, false,
                       nullptr, false, mod.wq_c0, -1, nullptr, nullptr, &gf);
             release(hr);
-            release(xr);
+            if (!fold_sc) release(xr);
         }
         Tn out;
         // The two fusions above were requested from PREDICTED shapes / types; Conv_1 is decided from the tensors that exist:
@@ -462,18 +497,31 @@ struct Builder {
             gn_release(gf.g);
             gf.done = false;
         }
-        const Tn* resid = sp.valid ? nullptr : (xs.valid() ? &xs : &x1);
+        const Tn* resid = (sp.valid || fold_sc) ? nullptr : (xs.valid() ? &xs : &x1);
         const SkPartial* extra = sp.valid ? &sp : nullptr;
+        ScFold fo;
+        if (fold_sc) {
+            fo.s1 = (mod.up || mod.down) ? &xr : &x1;
+            fo.s2 = (mod.up || mod.down) ? nullptr : x2;
+            fo.w = mod.w_c2;
+            fo.bias = mod.w_c2_b;
+        }
+        const ScFold* fold = fold_sc ? &fo : nullptr;
+        if (fold && ((gf.done && gf.apply) || !fusable(h1, 0))) {
+            set_error("internal: shortcut fold planned for a Conv_1 that does not normalise on load");
+            failed = true;
+        }
         if (gf.done && gf.apply) {                       // h1 already is act(GroupNorm_1(Conv_0(.)))
             out = conv("conv1_3x3", h1, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, resid, rs2, false, false, nullptr,
                        false, -1, -1, nullptr, extra);
             release(h1);
         } else if (fusable(h1, 0)) {
             GnBuf g1 = gf.done ? gf.g : gn(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b);
-            out = conv("conv1_3x3_gn", h1, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, resid, rs2,
-                       false, false, &g1, true, mod.wq_c1, -1, nullptr, extra);
+            out = conv(fold ? "conv1_3x3_gn_sc" : "conv1_3x3_gn", h1, nullptr, mod.w_c1, mod.w_c1_b, -1, mod.out_ch, 9, resid, rs2,
+                       false, false, &g1, true, mod.wq_c1, -1, nullptr, extra, nullptr, fold);
             gn_release(g1);
             release(h1);
+            if (fold && (mod.up || mod.down)) release(xr);
         } else {
             Tn h2 = gn_norm(h1, nullptr, mod.w_gn1_g, mod.w_gn1_b, true);
             release(h1);

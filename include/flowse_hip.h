@@ -225,6 +225,18 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
                         const float* res, const float* gn_mean, const float* gn_scale, const float* gn_beta, int silu,
                         float* out, int B, int H, int W, int Cout, int taps, float scale, int dt, void* scratch,
                         int64_t scratch_bytes, void* stream);
+/* Tail of ResnetBlockBigGANpp (layerspp.py:265-274) in 16-bit storage as ONE launch of the producer / consumer kernel:
+ *   out = (conv3x3(act(GroupNorm(h)); w1) + b1 + conv1x1(cat[x1, x2]; w2) + b2) * scale
+ * The 1x1 shortcut Conv_2(x) runs as extra K steps of Conv_1's launch (the form the 16-bit model modes use wherever
+ * Conv_1 is on that kernel; FLOWSE_NO_SCFOLD=1 at plan time restores the separate launch).  h: [B][H][W][C] with per-
+ * (sample, channel) gn_mean / gn_scale [B][C] and gn_beta [C] (NULL: no normalisation); w1 [Cout][9][C]; x1 / x2 (NULL)
+ * the shortcut's input channels (XC1, XC2 multiples of 32, >= 96 in all), w2 [Cout][1][XC1 + XC2].  Shapes: H, W
+ * multiples of 16, C % 32 == 0, Cout % 128 == 0, at least 64 (16 x 16 tile, 128-channel block) items, else
+ * FLOWSE_ERR_SHAPE.  `scratch`: 2 * (h + x1 + x2 + 2 w1 + 2 w2 + out elements) + 4 KB bytes. */
+int flowse_op_resblock_tail_16(const float* h, int C, const float* gn_mean, const float* gn_scale, const float* gn_beta,
+                               int silu, const float* w1, const float* b1, const float* x1, int XC1, const float* x2,
+                               int XC2, const float* w2, const float* b2, float* out, int B, int H, int W, int Cout,
+                               float scale, int dt, void* scratch, int64_t scratch_bytes, void* stream);
 /* Fused ResnetBlock half:  out = (conv3x3(act(GroupNorm(cat[in1,in2]))) + bias + bias2[b] + res) * scale
  * (layerspp.py:246-249 / :265-267) with the normalisation + SiLU applied while the input tile is staged into LDS.
  * Only for shapes the halo kernel covers (H % 8 == 0, W % 16 == 0, C1 % 32 == 0, C2 % 32 == 0, image large

@@ -488,3 +488,59 @@ def test_conv2d_16bit_storage(case, dt, bound):
     err = float((got - ref).norm() / ref.norm())
     print(f"conv2d_16 {case} dt={dt}: rel-L2 vs fp32 torch {err:.3e}")
     assert err < bound
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The 1x1 shortcut folded into Conv_1's launch (flowse_op_resblock_tail_16 -> ConvArgs::sc1 in conv3x3_pc16_kernel):
+# out = (conv3x3(act(GroupNorm(h))) + b1 + conv1x1(cat[x1, x2]) + b2) / sqrt(2), layerspp.py:265-274.  Reference = torch
+# fp32 of the unrounded tensors; ceilings as in test_conv2d_16bit_storage.  Shortcut step counts 4 / 8 / 12 / 16 cover
+# every remainder of the three-entry fragment ring; one or two source tensors; blocks with several tiles.
+TAIL_CASES = {"up_256to128": (2, 128, 128, 128, 128, 64, 128), "one_source_8": (1, 128, 256, 0, 128, 128, 128),
+              "steps4_256out": (2, 256, 128, 0, 256, 64, 64), "steps12": (1, 128, 256, 128, 128, 128, 128),
+              "steps16": (2, 256, 256, 256, 256, 64, 64), "ragged_items": (3, 64, 96, 32, 256, 112, 128),
+              "no_gn": (1, 128, 128, 0, 128, 128, 128)}
+
+
+@pytest.mark.parametrize("dt,bound", [(1, 4e-3), (2, 5e-4)])
+@pytest.mark.parametrize("case", sorted(TAIL_CASES))
+def test_resblock_tail_16bit_shortcut_fold(case, dt, bound):
+    import _gpu as G
+    from flowmse_amd import _lib
+    L = _lib.lib
+    B, C, X1, X2, Cout, H, W = TAIL_CASES[case]
+    g = torch.Generator().manual_seed(11)
+    h = torch.randn(B, C, H, W, generator=g)
+    x = torch.randn(B, X1 + X2, H, W, generator=g)
+    w1 = torch.randn(Cout, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    w2 = torch.randn(Cout, X1 + X2, 1, 1, generator=g) / (X1 + X2) ** 0.5
+    b1, b2 = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    mean = scl = beta = None
+    hin = h
+    if case != "no_gn":
+        mean = 0.2 * torch.randn(B, C, generator=g)
+        scl = 1 + 0.2 * torch.randn(B, C, generator=g)
+        beta = 0.2 * torch.randn(C, generator=g)
+        hin = F.silu((h - mean[:, :, None, None]) * scl[:, :, None, None] + beta[None, :, None, None])
+    ref = (F.conv2d(hin, w1, b1, padding=1) + F.conv2d(x, w2, b2)) * 0.7071
+    hd = G.nhwc(h)
+    x1d = G.nhwc(x[:, :X1].contiguous())
+    x2d = G.nhwc(x[:, X1:].contiguous()) if X2 else None
+    w1p = w1.permute(0, 2, 3, 1).reshape(Cout, 9, C).contiguous().cuda()
+    w2p = w2.reshape(Cout, 1, X1 + X2).contiguous().cuda()
+    md, sd, bd = ((t.contiguous().cuda() for t in (mean, scl, beta)) if mean is not None else (None, None, None))
+    b1d, b2d = b1.cuda(), b2.cuda()                          # (named: a temporary's block would be handed to the next allocation)
+    out = torch.empty(B, H, W, Cout, device="cuda")
+    scratch = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    _lib.check(L.flowse_op_resblock_tail_16(_lib.ptr(hd), C, _lib.ptr(md), _lib.ptr(sd), _lib.ptr(bd), 1, _lib.ptr(w1p),
+                                            _lib.ptr(b1d), _lib.ptr(x1d), X1, _lib.ptr(x2d), X2, _lib.ptr(w2p),
+                                            _lib.ptr(b2d), _lib.ptr(out), B, H, W, Cout, 0.7071, dt, _lib.ptr(scratch),
+                                            scratch.numel(), G.stream()))
+    torch.cuda.synchronize()
+    got = G.nchw(out)
+    err = float((got - ref).norm() / ref.norm())
+    print(f"resblock_tail_16 {case} dt={dt}: rel-L2 vs fp32 torch {err:.3e}")
+    if err >= bound:                       # which term is off?
+        r1, r2 = F.conv2d(hin, w1, b1, padding=1) * 0.7071, F.conv2d(x, w2, b2) * 0.7071
+        print("  vs conv3x3 term alone", float((got - r1).norm() / r1.norm()), " vs shortcut alone", float((got - r2).norm() / r2.norm()))
+    assert err < bound
+
