@@ -70,6 +70,7 @@ SIGNATURES = {
                                 _vp]),
     "flowse_op_resblock_tail_16": (_i, [_fp, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _f,
                                        _i, _vp, _i64, _vp]),
+    "flowse_op_pc16_channel_blocks": (_i, [_i]),
     "flowse_op_conv2d_scratch_floats": (_i64, [_i, _i, _i, _i, _i, _i]),
     "flowse_op_conv3x3_gn": (_i, [_fp, _i, _fp, _i, _fp, _fp, _f, _i, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _fp, _vp]),
     "flowse_op_conv3x3_f43": (_i, [_fp, _i, _fp, _i, _fp, _fp, _f, _i, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _fp, _vp]),

@@ -292,6 +292,7 @@ int conv16_ksplit(int B, int H, int W, int Cin, int Cout, int taps);
 // true when a 3x3 conv with 16-bit operands runs the LDS-halo kernel (fused GroupNorm input possible, statistics of the
 // output fused, H*W/128 partial blocks); otherwise the flat 16-bit kernel (+ split-K) takes it
 bool conv16_uses_halo(int B, int H, int W, int C1, int C2, int Cout, int taps);
+void pc16_set_channel_blocks(int mode);                                           // flowse_op_pc16_channel_blocks
 bool conv16_uses_pc(int B, int H, int W, int C1, int C2, int Cout, int taps);     // ... and the producer / consumer form of it (needs ConvArgs::wfrag)
 // number of per-sample partial-statistics blocks the 16-bit conv path writes for this shape (0 = none)
 int conv16_stats_blocks(int B, int H, int W, int Cin, int Cout, int taps);

@@ -92,9 +92,12 @@ struct PcOut {
     unsigned voff;
     int rowb, cstep;                                       // bytes per image row / per 8 pixels of a row
 };
-// pixel (pl + 8 k) of row pair (t, i): row = y0 + 8 t + 2 (2 wm + i) + (k >> 1), column = x0 + pl + 8 (k & 1)
+// NJ = 2: pixel (pl + 8 k) of row pair (t, i): row = y0 + 8 t + 2 (2 wm + i) + (k >> 1), column = x0 + pl + 8 (k & 1);
+// NJ = 1: pixel (pl + 16 k): row = ... + k, column = x0 + pl
+template <int NJ>
 __device__ __forceinline__ unsigned pc_osoff(const PcOut& o, int t, int i, int k) {
-    return (unsigned)__builtin_amdgcn_readfirstlane((8 * t + 2 * i + (k >> 1)) * o.rowb + (k & 1) * o.cstep);
+    if (NJ == 2) return (unsigned)__builtin_amdgcn_readfirstlane((8 * t + 2 * i + (k >> 1)) * o.rowb + (k & 1) * o.cstep);
+    return (unsigned)__builtin_amdgcn_readfirstlane((8 * t + 2 * i + k) * o.rowb);
 }
 // Residuals and the next tile's B-fragment ring share the ring's 48 registers (explicitly: left to the allocator, early
 // residual requests were spilled to scratch behind an s_waitcnt vmcnt(0)).  Round r = 2 t + i of the stage:
@@ -104,15 +107,23 @@ __device__ __forceinline__ unsigned pc_osoff(const PcOut& o, int t, int i, int k
 //   goes into wb[0] when round 0 has consumed it;
 // The next tile's first three ring entries are requested by the caller AFTER the stage (requested from inside it, into the
 // registers of consumed residuals, they were spilled as well): ~700 cycles of L2 latency per tile stay exposed.
-template <class OT, bool RES>
-__device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2][2][2], float* T, float* red, int b, int y0,
-                                              int x0, int n0, int tiles_x, bf16x8 (&wb)[3][2][2], const PcOut& po) {
+// NJ = 32-channel tiles per wave (2: 128-channel blocks; 1: 64-channel blocks for launches with too few items to fill the
+// chip, see launch_pc16): the transposition tile is [32 px][32 NJ ch], a lane reads 8 channels of the pixels pl + PL k.
+#define FLOWSE_PC_WBK(R, K) wb[R][NJ == 2 ? ((K) >> 1) : (K)][NJ == 2 ? ((K) & 1) : 0]   /* k-th 16-byte residual piece of a round */
+template <class OT, bool RES, int NJ>
+__device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2][2][NJ], float* T, float* red, int b, int y0,
+                                              int x0, int n0, int tiles_x, bf16x8 (&wb)[3][2][NJ], const PcOut& po) {
+    constexpr int OCT = 4 * NJ;                            // channel octets of the wave's tile
+    constexpr int PL = 64 / OCT;                           // pixel lanes
+    constexpr int KN = 32 / PL;                            // pixels per lane and (t, i) round
+    constexpr int NCH = 64 * NJ;                           // channels of the block
+    constexpr int TP = 32 * NJ + 4;                        // floats per pixel row of the transposition tile (+ 16 B)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kh = lane >> 5;
-    const int o = lane & 7, pl = lane >> 3;                // read side: channel octet, pixel lane (pixels pl + 8 k)
+    const int o = lane & (OCT - 1), pl = lane / OCT;       // read side: channel octet, pixel lane (pixels pl + PL k)
     const int Cout = a.Cout;
-    const int ch0 = n0 + wn * 64 + o * 8;                  // this lane's 8 output channels
+    const int ch0 = n0 + wn * (32 * NJ) + o * 8;           // this lane's 8 output channels
     f32x2 bq[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) bq[e] = a.bias ? f32x2{a.bias[ch0 + 2 * e], a.bias[ch0 + 2 * e + 1]} : f32x2{0.f, 0.f};
@@ -135,20 +146,20 @@ __device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2
         for (int i = 0; i < 2; ++i) {
             // accumulators -> T[pixel][channel]: register r of tile j = pixel (r & 3) + 8 (r >> 2) + 4 kh, channel 32 j + li
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kh) * PCW_PITCH + j * 32 + li] = acc[t][i][j][r];
+                for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kh) * TP + j * 32 + li] = acc[t][i][j][r];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 lo = *reinterpret_cast<const float4*>(T + (pl + 8 * k) * PCW_PITCH + o * 8);
-                const float4 hi = *reinterpret_cast<const float4*>(T + (pl + 8 * k) * PCW_PITCH + o * 8 + 4);
+            for (int k = 0; k < KN; ++k) {
+                const float4 lo = *reinterpret_cast<const float4*>(T + (pl + PL * k) * TP + o * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(T + (pl + PL * k) * TP + o * 8 + 4);
                 f32x2 v[4] = {f32x2{lo.x, lo.y}, f32x2{lo.z, lo.w}, f32x2{hi.x, hi.y}, f32x2{hi.z, hi.w}};
                 unsigned w[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x2 x = v[q] + bq[q];
                     if (RES) {
-                        const u32x4 rr = __builtin_bit_cast(u32x4, wb[(2 * t + i) % 3][k >> 1][k & 1]);
+                        const u32x4 rr = __builtin_bit_cast(u32x4, FLOWSE_PC_WBK((2 * t + i) % 3, k));
                         const unsigned rw = q == 0 ? rr.x : q == 1 ? rr.y : q == 2 ? rr.z : rr.w;
                         float r0, r1;
                         St<OT>::unpack2(rw, r0, r1);
@@ -164,24 +175,25 @@ __device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2
                     s1[q] += d;
                     s2[q] = __builtin_elementwise_fma(d, d, s2[q]);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, po.rs_out, po.voff, pc_osoff(po, t, i, k), 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, po.rs_out, po.voff, pc_osoff<NJ>(po, t, i, k), 0);
                 if (RES && t == 0 && i == 0)                // round 3's residual into the registers round 0 just read
-                    wb[0][k >> 1][k & 1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                        po.rs_res, po.voff, pc_osoff(po, 1, 1, k), 0));
+                    FLOWSE_PC_WBK(0, k) = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        po.rs_res, po.voff, pc_osoff<NJ>(po, 1, 1, k), 0));
             }
         }
         if (!a.stats) continue;
-        // 8 values per lane and channel -> the 8 pixel lanes of the octet (64 = this wave's pixels of sub-tile t)
+        // 2 KN values per lane and channel -> the PL pixel lanes of the octet (64 = this wave's pixels of sub-tile t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float pv = (e & 1) ? piv[e >> 1].y : piv[e >> 1].x;
             const float a1 = (e & 1) ? s1[e >> 1].y : s1[e >> 1].x;
             const float a2 = (e & 1) ? s2[e >> 1].y : s2[e >> 1].x;
-            float mean = pv + a1 * 0.125f;
-            float m2 = fmaxf(a2 - a1 * a1 * 0.125f, 0.f);
-            float cnt = 8.f;
+            constexpr float inv = 1.f / (2 * KN);
+            float mean = pv + a1 * inv;
+            float m2 = fmaxf(a2 - a1 * a1 * inv, 0.f);
+            float cnt = (float)(2 * KN);
 #pragma unroll
-            for (int off = 8; off < 64; off <<= 1) {
+            for (int off = OCT; off < 64; off <<= 1) {
                 const float mo = __shfl_xor(mean, off), qo = __shfl_xor(m2, off);
                 const float d = mo - mean;
                 m2 = m2 + qo + d * d * (0.5f * cnt);
@@ -189,7 +201,7 @@ __device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2
                 cnt *= 2.f;
             }
             if (pl == 0) {
-                float* dst = red + (((wm * 2 + t) * 128) + wn * 64 + o * 8 + e) * 2;
+                float* dst = red + (((wm * 2 + t) * NCH) + wn * (32 * NJ) + o * 8 + e) * 2;
                 dst[0] = mean;
                 dst[1] = m2;
             }
@@ -197,12 +209,12 @@ __device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2
     }
     __syncthreads();                                       // (S) always: the producers match it
     if (!a.stats) return;
-    if (tid < 128) {
+    if (tid < NCH) {
         const int tile0 = (y0 >> 3) * tiles_x + (x0 >> 4);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const float ma = red[((0 * 2 + t) * 128 + tid) * 2], qa = red[((0 * 2 + t) * 128 + tid) * 2 + 1];
-            const float mb = red[((1 * 2 + t) * 128 + tid) * 2], qb = red[((1 * 2 + t) * 128 + tid) * 2 + 1];
+            const float ma = red[((0 * 2 + t) * NCH + tid) * 2], qa = red[((0 * 2 + t) * NCH + tid) * 2 + 1];
+            const float mb = red[((1 * 2 + t) * NCH + tid) * 2], qb = red[((1 * 2 + t) * NCH + tid) * 2 + 1];
             const float d = mb - ma;
             float* dst = a.stats + (((int64_t)b * a.stats_nblk + tile0 + t * tiles_x) * Cout + n0 + tid) * 2;
             dst[0] = 0.5f * (ma + mb);
@@ -211,8 +223,9 @@ __device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2
     }
 }
 
-template <int GN, bool F16>
+template <int GN, bool F16, int NJ>
 __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
+    constexpr int NCH = 64 * NJ;                           // output channels per block (NJ 32-channel tiles per consumer wave)
     using T16 = typename std::conditional<F16, f16_t, bf16_t>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     PC_TS_ENTRY
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     // addressing reads the centre pixel, no GroupNorm; B fragments = the 1x1 weights in the same fragment order
     const int ns = (a.SC1 + a.SC2) / KC;
     const int nct = nchunks + ns;                          // chunks per tile in this block's stream
-    const int n_ntiles = a.Cout >> 7;
+    const int n_ntiles = a.Cout / NCH;
     const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 4);
     // ---- this block's items: XCD x (= blockIdx & 7, where the dispatcher puts the block) walks the contiguous item range
     // [I x / 8, I (x + 1) / 8) with its gridDim / 8 blocks interleaved, so neighbouring tiles (shared halo rows, the same
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         const int ty = tt / tiles_x;
         p.y0 = ty * 16;
         p.x0 = (tt - ty * tiles_x) * 16;
-        p.n0 = nt * 128;
+        p.n0 = nt * NCH;
         return p;
     };
 
@@ -290,14 +303,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
                 w1 = w0 + jshort;
             }
         };
-        f32x16 acc[2][2][2];
+        f32x16 acc[2][2][NJ];
         auto zero_acc = [&]() {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
         };
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         // before the MFMAs of half-step h (two sets of 4); the B fragments of a whole step travel through a ring of three
         // register sets, i.e. they are requested three steps (>= 1 500 cycles) before their MFMAs.
         bf16x8 xa[2][2], ya[2][2];                         // [t][i]
-        bf16x8 wb[3][2][2];                                // [ring][mh][j]
+        bf16x8 wb[3][2][NJ];                               // [ring][mh][j]
 
 #define FLOWSE_PC_LOADA(FA, HOFF, TAP, MH)                                                                           \
     {                                                                                                                \
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
             FA[t][i] = *reinterpret_cast<const bf16x8*>(Hb + abase[i] + t * 8 * PC_HPITCH);                          \
     }
 #define FLOWSE_PC_WLOAD(RING, S0, S1, TAPV)                                                                          \
-    _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) _Pragma("unroll") for (int j = 0; j < 2; ++j)                   \
+    _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                  \
         wb[RING][mh][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                          \
             rsrcw, bvo, (j ? (S1) : (S0)) + (unsigned)((TAPV) * PCF_STEP + mh * 1024), 0));
         // One step at tap TAP of the current chunk (halo buffer offset hoff, B ring entry R = TAP % 3): 16 MFMAs with every other
@@ -348,7 +361,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     if constexpr ((TAP) + 3 < 9) { FLOWSE_PC_W1(R, MH, J_, wc0, wc1, (TAP) + 3) } else { FLOWSE_PC_W1(R, MH, J_, wn0, wn1, (TAP) + 3 - 9) }
 #define FLOWSE_PC_NEXTA(T_, I_, TAP)                                                                                 \
     if constexpr ((TAP) < 8) { FLOWSE_PC_A1(xa, T_, I_, hoff, (TAP) + 1, 0) } else { FLOWSE_PC_A1(xa, T_, I_, hnext, 0, 0) }
+        // NJ = 1 (64-channel blocks): eight MFMAs per step, every A fragment requested four MFMAs ahead of its use
+#define FLOWSE_PC_STEP_N1(TAP)                                                                                       \
+    {                                                                                                                \
+        constexpr int R = (TAP) % 3;                                                                                 \
+        FLOWSE_PC_M1(xa, 0, 0, 0, R, 0) FLOWSE_PC_A1(ya, 0, 0, hoff, (TAP), 1)                                       \
+        FLOWSE_PC_M1(xa, 0, 1, 0, R, 0) FLOWSE_PC_A1(ya, 0, 1, hoff, (TAP), 1)                                       \
+        FLOWSE_PC_M1(xa, 1, 0, 0, R, 0) FLOWSE_PC_A1(ya, 1, 0, hoff, (TAP), 1)                                       \
+        FLOWSE_PC_M1(xa, 1, 1, 0, R, 0) FLOWSE_PC_A1(ya, 1, 1, hoff, (TAP), 1) FLOWSE_PC_REFILL(R, 0, 0, TAP)        \
+        FLOWSE_PC_M1(ya, 0, 0, 0, R, 1) FLOWSE_PC_NEXTA(0, 0, TAP)                                                   \
+        FLOWSE_PC_M1(ya, 0, 1, 0, R, 1) FLOWSE_PC_NEXTA(0, 1, TAP)                                                   \
+        FLOWSE_PC_M1(ya, 1, 0, 0, R, 1) FLOWSE_PC_NEXTA(1, 0, TAP)                                                   \
+        FLOWSE_PC_M1(ya, 1, 1, 0, R, 1) FLOWSE_PC_NEXTA(1, 1, TAP) FLOWSE_PC_REFILL(R, 1, 0, TAP)                    \
+    }
+#define FLOWSE_PC_SSTEP_N1(R)                                                                                        \
+    {                                                                                                                \
+        FLOWSE_PC_M1(xa, 0, 0, 0, R, 0) FLOWSE_PC_A1(ya, 0, 0, hoff, 0, 1)                                           \
+        FLOWSE_PC_M1(xa, 0, 1, 0, R, 0) FLOWSE_PC_A1(ya, 0, 1, hoff, 0, 1)                                           \
+        FLOWSE_PC_M1(xa, 1, 0, 0, R, 0) FLOWSE_PC_A1(ya, 1, 0, hoff, 0, 1)                                           \
+        FLOWSE_PC_M1(xa, 1, 1, 0, R, 0) FLOWSE_PC_A1(ya, 1, 1, hoff, 0, 1) FLOWSE_PC_W1(R, 0, 0, wn0, wn1, 0)        \
+        FLOWSE_PC_M1(ya, 0, 0, 0, R, 1) FLOWSE_PC_A1(xa, 0, 0, hnext, 0, 0)                                          \
+        FLOWSE_PC_M1(ya, 0, 1, 0, R, 1) FLOWSE_PC_A1(xa, 0, 1, hnext, 0, 0)                                          \
+        FLOWSE_PC_M1(ya, 1, 0, 0, R, 1) FLOWSE_PC_A1(xa, 1, 0, hnext, 0, 0)                                          \
+        FLOWSE_PC_M1(ya, 1, 1, 0, R, 1) FLOWSE_PC_A1(xa, 1, 1, hnext, 0, 0) FLOWSE_PC_W1(R, 1, 0, wn0, wn1, 0)       \
+    }
 #define FLOWSE_PC_STEP(TAP)                                                                                          \
+    if constexpr (NJ == 1) FLOWSE_PC_STEP_N1(TAP) else                                                               \
     {                                                                                                                \
         constexpr int R = (TAP) % 3;                                                                                 \
         FLOWSE_PC_M1(xa, 0, 0, 0, R, 0) FLOWSE_PC_A1(ya, 0, 0, hoff, (TAP), 1)                                       \
@@ -372,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         // chunk's pixels are staged unshifted --, the refill of entry R comes from the shortcut step three ahead (wn0 / wn1, the
         // last one again past the end) and the next A fragments from the next chunk's buffer.
 #define FLOWSE_PC_SSTEP(R)                                                                                           \
+    if constexpr (NJ == 1) FLOWSE_PC_SSTEP_N1(R) else                                                                \
     {                                                                                                                \
         FLOWSE_PC_M1(xa, 0, 0, 0, R, 0) FLOWSE_PC_A1(ya, 0, 0, hoff, 0, 1)                                           \
         FLOWSE_PC_M1(xa, 0, 0, 1, R, 0) FLOWSE_PC_A1(ya, 0, 1, hoff, 0, 1)                                           \
@@ -392,9 +431,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     }
 #define FLOWSE_PC_RESLOAD(R)                               /* residual of output round R into ring entry R (see pc16_out_wide) */ \
     if (tile_end && has_res) {                                                                                       \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                \
-            wb[R][k >> 1][k & 1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                 \
-                po.rs_res, po.voff, pc_osoff(po, (R) >> 1, (R) & 1, k), 0));                                         \
+        _Pragma("unroll") for (int k = 0; k < 2 * NJ; ++k)                                                           \
+            FLOWSE_PC_WBK(R, k) = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                  \
+                po.rs_res, po.voff, pc_osoff<NJ>(po, (R) >> 1, (R) & 1, k), 0));                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
         PC_TS_DECL
@@ -412,12 +451,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
             const T16* rb = has_res ? reinterpret_cast<const T16*>(a.res) + sb : ob;
             po.rs_out = __builtin_amdgcn_make_buffer_rsrc(ob, 0, H * po.rowb, 0x00020000);
             po.rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<T16*>(rb), 0, H * po.rowb, 0x00020000);
-            po.voff = (unsigned)((((pit.y0 + 4 * wm) * W + pit.x0 + (lane >> 3)) * a.Cout + pit.n0 + wn * 64 + (lane & 7) * 8) * 2);
+            po.voff = (unsigned)((((pit.y0 + 4 * wm) * W + pit.x0 + lane / (4 * NJ)) * a.Cout + pit.n0 + wn * (32 * NJ) +
+                                  (lane & (4 * NJ - 1)) * 8) * 2);
         };
         set_out();
         int hoff = 0;                                      // byte offset of the current chunk's halo buffer
-        int nb_cur = (pit.n0 >> 5) + wn * 2;               // this wave's first 32-channel block in the current / the next item
-        auto nb_of = [&](int k) { return ((first + k * G8) % n_ntiles) * 4 + wn * 2; };
+        int nb_cur = (pit.n0 >> 5) + wn * NJ;              // this wave's first 32-channel block in the current / the next item
+        auto nb_of = [&](int k) { return ((first + k * G8) % n_ntiles) * (2 * NJ) + wn * NJ; };
         int nb_next = nb_of(min(1, n_items - 1));
         unsigned wc0, wc1, wn0, wn1;                       // scalar byte offsets: this chunk's fragments (block j = 0 / 1), the next one's
         chunk_off(nb_cur, 0, wc0, wc1);
@@ -465,8 +505,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
                 }
                 // the tile is complete: output stage (its block barrier (S) is matched by the producers), next tile
                 const PcItem p = pit;
-                if (has_res) pc16_out_wide<T16, true>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x, wb, po);
-                else pc16_out_wide<T16, false>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x, wb, po);
+                if (has_res) pc16_out_wide<T16, true, NJ>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x, wb, po);
+                else pc16_out_wide<T16, false, NJ>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x, wb, po);
                 zero_acc();
                 cit = 0;
                 ++kitem;
@@ -487,6 +527,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         if (wave == 0) { PC_TS_FLUSH(0) }                  // slots 0-7 of the block
 #undef FLOWSE_PC_RESLOAD
 #undef FLOWSE_PC_SSTEP
+#undef FLOWSE_PC_SSTEP_N1
+#undef FLOWSE_PC_STEP_N1
 #undef FLOWSE_PC_STEP
 #undef FLOWSE_PC_NEXTA
 #undef FLOWSE_PC_REFILL
@@ -757,6 +799,14 @@ bool conv16_uses_pc(int B, int H, int W, int C1, int C2, int Cout, int taps) {
     return ((int64_t)B * H * W / 256) * (Cout / 128) >= 64;
 }
 
+// FLOWSE_PC16_NARROW=0 / 1: never / always 64-channel blocks (A-B hook); default: below 3/4 of an item per CU
+static int g_pc_narrow = getenv("FLOWSE_PC16_NARROW") ? atoi(getenv("FLOWSE_PC16_NARROW")) : -1;
+void pc16_set_channel_blocks(int mode) { g_pc_narrow = mode < 0 ? -1 : (mode != 0); }
+static bool pc16_narrow(int64_t items128, int cus) {
+    if (g_pc_narrow >= 0) return g_pc_narrow != 0;
+    return items128 * 4 < (int64_t)cus * 3;
+}
+
 int launch_pc16(const ConvArgs& a, hipStream_t s) {
     if (a.in_dt == DT_F32 || a.in_dt != a.out_dt || a.terms != 1 || a.partial || !a.wq || !a.wfrag ||
         (a.wq_f16 ? DT_F16 : DT_BF16) != a.in_dt || !conv16_uses_pc(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
@@ -786,14 +836,23 @@ int launch_pc16(const ConvArgs& a, hipStream_t s) {
         cu_cache[dev & 63] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     cus = cu_cache[dev & 63];
-    const int64_t items = ((int64_t)a.B * a.H * a.W / 256) * (a.Cout / 128);
+    // 64-channel blocks (NJ = 1) when the 128-channel items would leave a quarter of the CUs or more idle (the 32 x 32 level
+    // at batch 8: 64 items -> 256): half the MFMAs per A fragment read from LDS, but four times the CUs at work
+    const int64_t items128 = ((int64_t)a.B * a.H * a.W / 256) * (a.Cout / 128);
+    const bool narrow = pc16_narrow(items128, cus);
+    const int64_t items = narrow ? 2 * items128 : items128;
     int grid = (int)(items < cus ? items : cus);
-    grid &= ~7;                                            // a multiple of the 8 XCDs (>= 256 items: never 0)
+    grid &= ~7;                                            // a multiple of the 8 XCDs (>= 64 items: never 0)
     const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;
-#define FLOWSE_LPC(GNF, F16)                                                                         \
-    {                                                                                                \
-        if (const int rc = allow_lds<&conv3x3_pc16_kernel<GNF, F16>>(PC_LDS)) return rc;             \
-        hipLaunchKernelGGL((conv3x3_pc16_kernel<GNF, F16>), dim3(grid), dim3(512), PC_LDS, s, a);    \
+#define FLOWSE_LPC(GNF, F16)                                                                                 \
+    {                                                                                                        \
+        if (narrow) {                                                                                        \
+            if (const int rc = allow_lds<&conv3x3_pc16_kernel<GNF, F16, 1>>(PC_LDS)) return rc;              \
+            hipLaunchKernelGGL((conv3x3_pc16_kernel<GNF, F16, 1>), dim3(grid), dim3(512), PC_LDS, s, a);     \
+        } else {                                                                                             \
+            if (const int rc = allow_lds<&conv3x3_pc16_kernel<GNF, F16, 2>>(PC_LDS)) return rc;              \
+            hipLaunchKernelGGL((conv3x3_pc16_kernel<GNF, F16, 2>), dim3(grid), dim3(512), PC_LDS, s, a);     \
+        }                                                                                                    \
     }
     if (a.wq_f16) {
         if (gn == 2) FLOWSE_LPC(2, true) else if (gn == 1) FLOWSE_LPC(1, true) else FLOWSE_LPC(0, true)

@@ -1074,6 +1074,11 @@ int flowse_op_resblock_tail_16(const float* h, int C, const float* gn_mean, cons
     return launch_convert(o16, dt, out, DT_F32, M * Cout, s);
 }
 
+int flowse_op_pc16_channel_blocks(int mode) {
+    pc16_set_channel_blocks(mode);
+    return OK;
+}
+
 int flowse_op_fir_up(const float* in, float* out, int B, int H, int W, int C, void* stream) {
     GnParams p{nullptr, nullptr, nullptr};
     return launch_fir_up(in, B, H, W, C, p, 0, nullptr, out, static_cast<hipStream_t>(stream));

@@ -16,7 +16,8 @@ extern "C" int flowse_debug_pc_ts(unsigned long long* host, int n) {
 #define PC_TS_ENTRY const unsigned long long pc_e0 = __builtin_amdgcn_s_memtime(), pc_r0 = __builtin_amdgcn_s_memrealtime();
 #define PC_TS_EXIT                                                  \
     pc_acc[5] = __builtin_amdgcn_s_memtime() - pc_e0;               \
-    pc_acc[6] = __builtin_amdgcn_s_memrealtime() - pc_r0;
+    pc_acc[6] = __builtin_amdgcn_s_memrealtime() - pc_r0;         \
+    pc_acc[7] = pc_r0;                                              /* absolute entry time (100 MHz): start skew between blocks */
 // add the time since the last mark to accumulator K
 #define PC_TS_ADD(K)                                               \
     {                                                              \

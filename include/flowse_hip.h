@@ -237,6 +237,11 @@ int flowse_op_resblock_tail_16(const float* h, int C, const float* gn_mean, cons
                                int silu, const float* w1, const float* b1, const float* x1, int XC1, const float* x2,
                                int XC2, const float* w2, const float* b2, float* out, int B, int H, int W, int Cout,
                                float scale, int dt, void* scratch, int64_t scratch_bytes, void* stream);
+/* Test / A-B hook, process-wide: channel-block width of conv3x3_pc16_kernel.  -1 (default): 128-channel blocks, 64-channel
+ * blocks for launches with fewer than 3/4 of a (16 x 16 tile, 128-channel block) item per compute unit; 0: always 128;
+ * 1: always 64 (also FLOWSE_PC16_NARROW=0 / 1 in the environment).  Results differ only in summation grouping of the
+ * GroupNorm partial statistics (the convolution sums are identical). */
+int flowse_op_pc16_channel_blocks(int mode);
 /* Fused ResnetBlock half:  out = (conv3x3(act(GroupNorm(cat[in1,in2]))) + bias + bias2[b] + res) * scale
  * (layerspp.py:246-249 / :265-267) with the normalisation + SiLU applied while the input tile is staged into LDS.
  * Only for shapes the halo kernel covers (H % 8 == 0, W % 16 == 0, C1 % 32 == 0, C2 % 32 == 0, image large

@@ -484,10 +484,17 @@ def test_conv2d_16bit_storage(case, dt, bound):
         gn = (mean, scl, beta)
         xin = F.silu((x - mean[:, :, None, None]) * scl[:, :, None, None] + beta[None, :, None, None])
     ref = (F.conv2d(xin, w, bias, padding=k // 2) + res) * 0.7071
-    got = _conv16(x[:, :C1].contiguous(), w, dt, bias, x[:, C1:].contiguous() if C2 else None, res, gn, 0.7071)
-    err = float((got - ref).norm() / ref.norm())
-    print(f"conv2d_16 {case} dt={dt}: rel-L2 vs fp32 torch {err:.3e}")
-    assert err < bound
+    # the producer / consumer kernel in both channel-block widths (128: NJ = 2, 64: NJ = 1), whatever the launch policy picks
+    from flowmse_amd import _lib
+    for blocks in ((0, 1) if case.startswith("pc") else (-1,)):
+        _lib.check(_lib.lib.flowse_op_pc16_channel_blocks(blocks))
+        try:
+            got = _conv16(x[:, :C1].contiguous(), w, dt, bias, x[:, C1:].contiguous() if C2 else None, res, gn, 0.7071)
+        finally:
+            _lib.check(_lib.lib.flowse_op_pc16_channel_blocks(-1))
+        err = float((got - ref).norm() / ref.norm())
+        print(f"conv2d_16 {case} dt={dt} blocks={blocks}: rel-L2 vs fp32 torch {err:.3e}")
+        assert err < bound
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -501,9 +508,10 @@ TAIL_CASES = {"up_256to128": (2, 128, 128, 128, 128, 64, 128), "one_source_8": (
               "no_gn": (1, 128, 128, 0, 128, 128, 128)}
 
 
+@pytest.mark.parametrize("blocks", [0, 1])
 @pytest.mark.parametrize("dt,bound", [(1, 4e-3), (2, 5e-4)])
 @pytest.mark.parametrize("case", sorted(TAIL_CASES))
-def test_resblock_tail_16bit_shortcut_fold(case, dt, bound):
+def test_resblock_tail_16bit_shortcut_fold(case, dt, bound, blocks):
     import _gpu as G
     from flowmse_amd import _lib
     L = _lib.lib
@@ -531,14 +539,18 @@ def test_resblock_tail_16bit_shortcut_fold(case, dt, bound):
     b1d, b2d = b1.cuda(), b2.cuda()                          # (named: a temporary's block would be handed to the next allocation)
     out = torch.empty(B, H, W, Cout, device="cuda")
     scratch = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
-    _lib.check(L.flowse_op_resblock_tail_16(_lib.ptr(hd), C, _lib.ptr(md), _lib.ptr(sd), _lib.ptr(bd), 1, _lib.ptr(w1p),
-                                            _lib.ptr(b1d), _lib.ptr(x1d), X1, _lib.ptr(x2d), X2, _lib.ptr(w2p),
-                                            _lib.ptr(b2d), _lib.ptr(out), B, H, W, Cout, 0.7071, dt, _lib.ptr(scratch),
-                                            scratch.numel(), G.stream()))
+    _lib.check(L.flowse_op_pc16_channel_blocks(blocks))      # 128- / 64-channel blocks (NJ = 2 / 1), whatever the policy picks
+    try:
+        _lib.check(L.flowse_op_resblock_tail_16(_lib.ptr(hd), C, _lib.ptr(md), _lib.ptr(sd), _lib.ptr(bd), 1, _lib.ptr(w1p),
+                                                _lib.ptr(b1d), _lib.ptr(x1d), X1, _lib.ptr(x2d), X2, _lib.ptr(w2p),
+                                                _lib.ptr(b2d), _lib.ptr(out), B, H, W, Cout, 0.7071, dt, _lib.ptr(scratch),
+                                                scratch.numel(), G.stream()))
+    finally:
+        _lib.check(L.flowse_op_pc16_channel_blocks(-1))
     torch.cuda.synchronize()
     got = G.nchw(out)
     err = float((got - ref).norm() / ref.norm())
-    print(f"resblock_tail_16 {case} dt={dt}: rel-L2 vs fp32 torch {err:.3e}")
+    print(f"resblock_tail_16 {case} dt={dt} blocks={blocks}: rel-L2 vs fp32 torch {err:.3e}")
     if err >= bound:                       # which term is off?
         r1, r2 = F.conv2d(hin, w1, b1, padding=1) * 0.7071, F.conv2d(x, w2, b2) * 0.7071
         print("  vs conv3x3 term alone", float((got - r1).norm() / r1.norm()), " vs shortcut alone", float((got - r2).norm() / r2.norm()))

@@ -62,9 +62,22 @@ def main():
              "cons: the same on the 100 MHz counter", "",
              "prod: requests", "prod: chunk barrier", "", "prod: output-stage wait", "prod: halo bursts",
              "prod: kernel entry -> loop end (ticks)", "prod: the same on the 100 MHz counter"]
+    live = t[:, 5] > 0                                       # blocks that ran (a launch may have fewer than 256)
     for k, n in enumerate(names):
         if n:
-            print(f"  {n:22s} median {np.median(t[:, k]):10.0f}  min {t[:, k].min():10.0f}  max {t[:, k].max():10.0f} cycles")
+            v = t[live, k]
+            print(f"  {n:22s} median {np.median(v):10.0f}  min {v.min():10.0f}  max {v.max():10.0f} cycles")
+    # start skew and per-block wall time (100 MHz counter -> us), by XCD (= blockIdx & 7)
+    idx = np.nonzero(live)[0]
+    t0 = t[live, 7] - t[live, 7].min()
+    dur = t[live, 6]
+    print(f"  blocks {live.sum()}: entry skew us  p50 {np.median(t0) / 100:.2f}  p90 {np.percentile(t0, 90) / 100:.2f}  max {t0.max() / 100:.2f};"
+          f"  duration us  p10 {np.percentile(dur, 10) / 100:.2f}  p50 {np.median(dur) / 100:.2f}  p90 {np.percentile(dur, 90) / 100:.2f}  max {dur.max() / 100:.2f};"
+          f"  last end {((t0 + dur).max()) / 100:.2f}")
+    for x in range(8):
+        m = (idx & 7) == x
+        if m.any():
+            print(f"    xcd {x}: n {m.sum():3d}  entry p50 {np.median(t0[m]) / 100:6.2f} max {t0[m].max() / 100:6.2f}   dur p50 {np.median(dur[m]) / 100:6.2f} max {dur[m].max() / 100:6.2f}")
 
 
 if __name__ == "__main__":
