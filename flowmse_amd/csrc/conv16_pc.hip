@@ -269,8 +269,182 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         return p;
     };
 
+    // ---- halo staging (the producers' job; in the prologue the consumer waves stage chunks 1 and 2 with the same piece map
+    // while the producers stage chunk 0: a one-item block spent a quarter of its time with its MFMA waves parked at the
+    // first barrier -- tools/pc16_ts.py: ~18 k of ~70 k cycles)
+    const int ltid = tid & 255;                            // staging thread: producers always, consumers in the prologue
+    const int octet = ltid & 3;                            // this thread's 8-channel group inside a 32-channel chunk
+    const int hp0 = ltid >> 2;                             // halo pixels hp0 + 64 q
+    // Per piece, fixed for the whole launch: its LDS byte offset inside a halo buffer and its byte offset inside the 18 x 18
+    // window of either source tensor.  Per (tile, chunk) only a descriptor, a scalar offset and six selects remain: the
+    // per-chunk window arithmetic and bounds tests (~100 VALU instructions) cost the staging waves as much as half a
+    // normalisation burst (tools/pc16_ts.py: "requests").
+    int hlds[PC_PIECES];
+    unsigned offA[PC_PIECES], offB[PC_PIECES];
+    unsigned pixo[PC_PIECES];                              // window pixel offset hy W + hx (the folded shortcut's sources)
+    unsigned smask = 0;                                    // pieces inside the 16 x 16 tile when the window is staged unshifted
+    unsigned hyx[PC_PIECES / 2];                           // window coordinates (hy | hx << 8), two per register: the per-tile bounds mask
+#pragma unroll
+    for (int q = 0; q < PC_PIECES; ++q) {
+        const int hp = hp0 + 64 * q;
+        const int hy = hp / 18, hx = hp - hy * 18;
+        hlds[q] = hy * PC_HPITCH + hx * PC_ROWB + octet * 16;
+        offA[q] = (unsigned)(((hy * W + hx) * C1 + octet * 8) * 2);
+        offB[q] = (unsigned)(((hy * W + hx) * C2 + octet * 8) * 2);
+        pixo[q] = (unsigned)(hy * W + hx);
+        if (hy < 16 && hx < 16) smask |= 1u << q;
+        const unsigned pk = (unsigned)hy | ((unsigned)hx << 8);
+        if (q & 1) hyx[q >> 1] |= pk << 16; else hyx[q >> 1] = pk;
+    }
+    const bool last_valid = hp0 + 64 * (PC_PIECES - 1) < 324;      // piece 5 exists for 16 threads only
+    const T16* in1p = reinterpret_cast<const T16*>(a.in1);
+    const T16* in2p = reinterpret_cast<const T16*>(a.in2);
+    const T16* sc1p = reinterpret_cast<const T16*>(a.sc1);
+    const T16* sc2p = reinterpret_cast<const T16*>(a.sc2);
+    const int SC1 = a.SC1, SC2 = a.SC2;
+    const int wpix = 17 * W + 18;
+
+    // stream position of the requests, advanced by one chunk per HLOAD (no division per request: every instruction of these
+    // waves competes with the MFMA stream for issue, ~10 cycles apiece): chunk rq_chunk of item rq_k, the item's coordinates
+    // and the in-image mask of this thread's pieces.  Beyond the stream's end the last chunk is requested again.
+    int rq_g = -1, rq_k = 0, rq_chunk = -1;
+    PcItem rq_p = item_at(0);
+    unsigned rq_mask = 0;
+    auto rq_item = [&]() {
+        unsigned m = 0;
+#pragma unroll
+        for (int q = 0; q < PC_PIECES; ++q) {
+            const unsigned hy = (hyx[q >> 1] >> ((q & 1) * 16)) & 0xffu, hx = (hyx[q >> 1] >> ((q & 1) * 16 + 8)) & 0xffu;
+            const bool in = (q < PC_PIECES - 1 || last_valid) && (unsigned)(rq_p.y0 - 1 + (int)hy) < (unsigned)H &&
+                            (unsigned)(rq_p.x0 - 1 + (int)hx) < (unsigned)W;
+            m |= in ? (1u << q) : 0u;
+        }
+        rq_mask = m;
+    };
+    rq_item();
+    auto rq_next = [&]() {
+        if (rq_g + 1 >= Ctot && rq_g >= 0) return;         // (uniform) clamp: stay on the last chunk
+        ++rq_g;
+        if (++rq_chunk == nct) {
+            rq_chunk = 0;
+            ++rq_k;
+            rq_p = item_at(rq_k);
+            rq_item();
+        }
+    };
+    // raw halo pieces (8 consecutive channels of a pixel per piece; out-of-image pixels read 0)
+    u32x4 ra[PC_PIECES], rb[PC_PIECES];                    // two chunks in flight
+    unsigned hin_a = 0, hin_b = 0;                         // in-image bits of the pieces held in ra / rb
+    // GroupNorm parameters of the thread's 8 channels, two chunks' worth
+    struct PcAff {
+        float4 m[2], s[2], b[2];
+    };
+    PcAff pa, pb;
+    // requests of the next stream chunk: raw pieces into R, their in-image bits into HIN, the GroupNorm parameters into Q
+#define FLOWSE_PC_HLOAD(R, HIN, Q)                                                                                   \
+    {                                                                                                                \
+        rq_next();                                                                                                   \
+        const int chunk = rq_chunk;                                                                                  \
+        const bool sc = chunk >= nchunks;                  /* a chunk of the folded shortcut: raw, unshifted */     \
+        const int c0 = (sc ? chunk - nchunks : chunk) * KC;                                                          \
+        const bool second = c0 >= (sc ? SC1 : C1);                                                                   \
+        const unsigned cs = (unsigned)(sc ? (second ? SC2 : SC1) : (second ? C2 : C1));                              \
+        const int64_t wbase = ((int64_t)rq_p.b * H + rq_p.y0 - (sc ? 0 : 1)) * W + rq_p.x0 - (sc ? 0 : 1);           \
+        const T16* srcp = sc ? (second ? sc2p : sc1p) : (second ? in2p : in1p);                                      \
+        const uint64_t wsel = reinterpret_cast<uint64_t>(srcp + wbase * (int64_t)cs);                                \
+        const uint64_t wuni = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wsel) |              \
+                              ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wsel >> 32)) << 32); \
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(                                       \
+            reinterpret_cast<T16*>(wuni), 0, __builtin_amdgcn_readfirstlane(wpix * (int)cs * 2), 0x00020000);        \
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((c0 - (second ? (sc ? SC1 : C1) : 0)) * 2);   \
+        const unsigned msk = sc ? smask : rq_mask;                                                                   \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
+            const unsigned offr = second ? offB[q] : offA[q];                                                        \
+            const unsigned offs = (pixo[q] * cs + (unsigned)octet * 8u) * 2u;                                        \
+            const unsigned off = ((msk >> q) & 1u) ? (sc ? offs : offr) : OOB;                                       \
+            R[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, soff, 0);                                        \
+        }                                                                                                            \
+        HIN = msk | (sc ? 0x80000000u : 0u);                                                                         \
+        if (!sc) load_params(rq_p.b, chunk, Q);                                                                      \
+    }
+    // GroupNorm parameters of (sample b, chunk): REQUESTED here (raw mean / scale / beta of the thread's 8 channels), folded by
+    // the burst that uses them a chunk later -- folded on arrival, every request waited ~1 900 cycles for these loads
+    auto load_params = [&](int b, int chunk, PcAff& q) {
+        if (!GN) return;
+        const int cg = chunk * KC + octet * 8;
+        const float* mp = a.gn.mean + (int64_t)b * Cin + cg;
+        const float* sp = a.gn.scale + (int64_t)b * Cin + cg;
+        const float* bp = a.gn.beta + cg;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            q.m[h] = *reinterpret_cast<const float4*>(mp + 4 * h);
+            q.s[h] = *reinterpret_cast<const float4*>(sp + 4 * h);
+            q.b[h] = *reinterpret_cast<const float4*>(bp + 4 * h);
+        }
+    };
+    // The raw pieces RX (parameters Q) of one chunk are normalised into the halo buffer at byte offset HB, stage by stage over
+    // ALL pieces (48 values): a lone wave hides no latency by itself -- piece after piece the dependent unpack -> fma -> exp ->
+    // rcp -> mul chains ran at ~10 cycles per instruction, 48 independent values per stage keep the VALU issuing.  SCALAR
+    // fp32 instructions on purpose (this translation unit is built with -fno-slp-vectorize): the staging now runs beside the
+    // consumers' MFMA stream, where a packed fp32 instruction costs ~20 cycles more than the two scalar ones it replaces
+    // (MI355X_MICROARCH.md; here: 26 k vs ... cycles of staging per tile, tools/pc16_ts.py).
+#define FLOWSE_PC_BURST(RX, HINX, Q, HB)                                                                             \
+    if (GN && !((HINX) >> 31)) {                                                                                     \
+        /* folded affine: y = (x - mean) scale + beta = x sc + sh; SiLU exponent -log2(e) y = x ec + eh */           \
+        float sc[8], sh[8], ec[8], eh[8];                                                                            \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                              \
+            const float mm[4] = {Q.m[h].x, Q.m[h].y, Q.m[h].z, Q.m[h].w}, ss[4] = {Q.s[h].x, Q.s[h].y, Q.s[h].z, Q.s[h].w}; \
+            const float bb[4] = {Q.b[h].x, Q.b[h].y, Q.b[h].z, Q.b[h].w};                                            \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
+                sc[4 * h + e] = ss[e];                                                                               \
+                sh[4 * h + e] = __builtin_fmaf(-mm[e], ss[e], bb[e]);                                                \
+                ec[4 * h + e] = -1.44269504088896341f * sc[4 * h + e];                                               \
+                eh[4 * h + e] = -1.44269504088896341f * sh[4 * h + e];                                               \
+            }                                                                                                        \
+        }                                                                                                            \
+        float v[PC_PIECES][8], z[PC_PIECES][8];                                                                      \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
+            const unsigned wsrc[4] = {RX[q].x, RX[q].y, RX[q].z, RX[q].w};                                           \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) St<T16>::unpack2(wsrc[e], v[q][2 * e], v[q][2 * e + 1]);   \
+        }                                                                                                            \
+        if (GN == 2) {                                                                                               \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
+                z[q][e] = __builtin_fmaf(v[q][e], ec[e], eh[e]);                                                     \
+        }                                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)          \
+            v[q][e] = __builtin_fmaf(v[q][e], sc[e], sh[e]);                                                         \
+        if (GN == 2) {                                                                                               \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
+                z[q][e] = __builtin_amdgcn_exp2f(z[q][e]);                                                           \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
+                z[q][e] += 1.f;                                                                                      \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
+                z[q][e] = __builtin_amdgcn_rcpf(z[q][e]);                                                            \
+            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
+                v[q][e] *= z[q][e];                                                                                  \
+        }                                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
+            const unsigned keepm = (((HINX) >> q) & 1u) ? 0xffffffffu : 0u;   /* zero padding AFTER the activation */ \
+            u32x4 t;                                                                                                 \
+            t.x = pc_pack2<F16>(v[q][0], v[q][1]) & keepm;                                                           \
+            t.y = pc_pack2<F16>(v[q][2], v[q][3]) & keepm;                                                           \
+            t.z = pc_pack2<F16>(v[q][4], v[q][5]) & keepm;                                                           \
+            t.w = pc_pack2<F16>(v[q][6], v[q][7]) & keepm;                                                           \
+            if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) + hlds[q]) = t;                 \
+        }                                                                                                            \
+    } else {                                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q)                                                        \
+            if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) + hlds[q]) = RX[q];             \
+    }
+
     if (wave < 4) {
         // ====================================================== consumers: A fragments from LDS, B fragments from L2, MFMA
+        // their share of the prologue: chunks 1 and 2 -> buffers 1 and 2 (the producers: chunk 0, the requests of chunks 3, 4)
+        rq_next();
+        FLOWSE_PC_HLOAD(ra, hin_a, pa)
+        FLOWSE_PC_HLOAD(rb, hin_b, pb)
+        FLOWSE_PC_BURST(ra, hin_a, pa, PC_HBUF_X)
+        FLOWSE_PC_BURST(rb, hin_b, pb, 2 * PC_HBUF_X)
         const int lane = tid & 63;
         const int wm = wave >> 1, wn = wave & 1;
         const int li = lane & 31, kh = lane >> 5;
@@ -448,9 +622,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         auto set_out = [&]() {                             // descriptors and lane offset of tile `pit`
             const int64_t sb = (int64_t)pit.b * H * W * a.Cout;
             T16* ob = reinterpret_cast<T16*>(a.out) + sb;
-            const T16* rb = has_res ? reinterpret_cast<const T16*>(a.res) + sb : ob;
+            const T16* rbase = has_res ? reinterpret_cast<const T16*>(a.res) + sb : ob;
             po.rs_out = __builtin_amdgcn_make_buffer_rsrc(ob, 0, H * po.rowb, 0x00020000);
-            po.rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<T16*>(rb), 0, H * po.rowb, 0x00020000);
+            po.rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<T16*>(rbase), 0, H * po.rowb, 0x00020000);
             po.voff = (unsigned)((((pit.y0 + 4 * wm) * W + pit.x0 + lane / (4 * NJ)) * a.Cout + pit.n0 + wn * (32 * NJ) +
                                   (lane & (4 * NJ - 1)) * 8) * 2);
         };
@@ -541,179 +715,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     }
 
     // =================================================================================== producers: halo staging
-    const int ltid = tid - 256;
-    const int octet = ltid & 3;                            // this thread's 8-channel group inside a 32-channel chunk
-    const int hp0 = ltid >> 2;                             // halo pixels hp0 + 64 q
-    // Per piece, fixed for the whole launch: its LDS byte offset inside a halo buffer and its byte offset inside the 18 x 18
-    // window of either source tensor.  Per (tile, chunk) only a descriptor, a scalar offset and six selects remain: the
-    // per-chunk window arithmetic and bounds tests (~100 VALU instructions) cost the staging waves as much as half a
-    // normalisation burst (tools/pc16_ts.py: "requests").
-    int hlds[PC_PIECES];
-    unsigned offA[PC_PIECES], offB[PC_PIECES];
-    unsigned pixo[PC_PIECES];                              // window pixel offset hy W + hx (the folded shortcut's sources)
-    unsigned smask = 0;                                    // pieces inside the 16 x 16 tile when the window is staged unshifted
-    unsigned hyx[PC_PIECES / 2];                           // window coordinates (hy | hx << 8), two per register: the per-tile bounds mask
-#pragma unroll
-    for (int q = 0; q < PC_PIECES; ++q) {
-        const int hp = hp0 + 64 * q;
-        const int hy = hp / 18, hx = hp - hy * 18;
-        hlds[q] = hy * PC_HPITCH + hx * PC_ROWB + octet * 16;
-        offA[q] = (unsigned)(((hy * W + hx) * C1 + octet * 8) * 2);
-        offB[q] = (unsigned)(((hy * W + hx) * C2 + octet * 8) * 2);
-        pixo[q] = (unsigned)(hy * W + hx);
-        if (hy < 16 && hx < 16) smask |= 1u << q;
-        const unsigned pk = (unsigned)hy | ((unsigned)hx << 8);
-        if (q & 1) hyx[q >> 1] |= pk << 16; else hyx[q >> 1] = pk;
-    }
-    const bool last_valid = hp0 + 64 * (PC_PIECES - 1) < 324;      // piece 5 exists for 16 threads only
-    const T16* in1p = reinterpret_cast<const T16*>(a.in1);
-    const T16* in2p = reinterpret_cast<const T16*>(a.in2);
-    const T16* sc1p = reinterpret_cast<const T16*>(a.sc1);
-    const T16* sc2p = reinterpret_cast<const T16*>(a.sc2);
-    const int SC1 = a.SC1, SC2 = a.SC2;
-    const int wpix = 17 * W + 18;
-
-    // stream position of the requests, advanced by one chunk per HLOAD (no division per request: every instruction of these
-    // waves competes with the MFMA stream for issue, ~10 cycles apiece): chunk rq_chunk of item rq_k, the item's coordinates
-    // and the in-image mask of this thread's pieces.  Beyond the stream's end the last chunk is requested again.
-    int rq_g = -1, rq_k = 0, rq_chunk = -1;
-    PcItem rq_p = item_at(0);
-    unsigned rq_mask = 0;
-    auto rq_item = [&]() {
-        unsigned m = 0;
-#pragma unroll
-        for (int q = 0; q < PC_PIECES; ++q) {
-            const unsigned hy = (hyx[q >> 1] >> ((q & 1) * 16)) & 0xffu, hx = (hyx[q >> 1] >> ((q & 1) * 16 + 8)) & 0xffu;
-            const bool in = (q < PC_PIECES - 1 || last_valid) && (unsigned)(rq_p.y0 - 1 + (int)hy) < (unsigned)H &&
-                            (unsigned)(rq_p.x0 - 1 + (int)hx) < (unsigned)W;
-            m |= in ? (1u << q) : 0u;
-        }
-        rq_mask = m;
-    };
-    rq_item();
-    auto rq_next = [&]() {
-        if (rq_g + 1 >= Ctot && rq_g >= 0) return;         // (uniform) clamp: stay on the last chunk
-        ++rq_g;
-        if (++rq_chunk == nct) {
-            rq_chunk = 0;
-            ++rq_k;
-            rq_p = item_at(rq_k);
-            rq_item();
-        }
-    };
-    // raw halo pieces (8 consecutive channels of a pixel per piece; out-of-image pixels read 0)
-    u32x4 ra[PC_PIECES], rb[PC_PIECES];                    // two chunks in flight
-    unsigned hin_a = 0, hin_b = 0;                         // in-image bits of the pieces held in ra / rb
-    // GroupNorm parameters of the thread's 8 channels, two chunks' worth
-    struct PcAff {
-        float4 m[2], s[2], b[2];
-    };
-    PcAff pa, pb;
-    // requests of the next stream chunk: raw pieces into R, their in-image bits into HIN, the GroupNorm parameters into Q
-#define FLOWSE_PC_HLOAD(R, HIN, Q)                                                                                   \
-    {                                                                                                                \
-        rq_next();                                                                                                   \
-        const int chunk = rq_chunk;                                                                                  \
-        const bool sc = chunk >= nchunks;                  /* a chunk of the folded shortcut: raw, unshifted */     \
-        const int c0 = (sc ? chunk - nchunks : chunk) * KC;                                                          \
-        const bool second = c0 >= (sc ? SC1 : C1);                                                                   \
-        const unsigned cs = (unsigned)(sc ? (second ? SC2 : SC1) : (second ? C2 : C1));                              \
-        const int64_t wbase = ((int64_t)rq_p.b * H + rq_p.y0 - (sc ? 0 : 1)) * W + rq_p.x0 - (sc ? 0 : 1);           \
-        const T16* srcp = sc ? (second ? sc2p : sc1p) : (second ? in2p : in1p);                                      \
-        const uint64_t wsel = reinterpret_cast<uint64_t>(srcp + wbase * (int64_t)cs);                                \
-        const uint64_t wuni = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wsel) |              \
-                              ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wsel >> 32)) << 32); \
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(                                       \
-            reinterpret_cast<T16*>(wuni), 0, __builtin_amdgcn_readfirstlane(wpix * (int)cs * 2), 0x00020000);        \
-        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((c0 - (second ? (sc ? SC1 : C1) : 0)) * 2);   \
-        const unsigned msk = sc ? smask : rq_mask;                                                                   \
-        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
-            const unsigned offr = second ? offB[q] : offA[q];                                                        \
-            const unsigned offs = (pixo[q] * cs + (unsigned)octet * 8u) * 2u;                                        \
-            const unsigned off = ((msk >> q) & 1u) ? (sc ? offs : offr) : OOB;                                       \
-            R[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, soff, 0);                                        \
-        }                                                                                                            \
-        HIN = msk | (sc ? 0x80000000u : 0u);                                                                         \
-        if (!sc) load_params(rq_p.b, chunk, Q);                                                                      \
-    }
-    // GroupNorm parameters of (sample b, chunk): REQUESTED here (raw mean / scale / beta of the thread's 8 channels), folded by
-    // the burst that uses them a chunk later -- folded on arrival, every request waited ~1 900 cycles for these loads
-    auto load_params = [&](int b, int chunk, PcAff& q) {
-        if (!GN) return;
-        const int cg = chunk * KC + octet * 8;
-        const float* mp = a.gn.mean + (int64_t)b * Cin + cg;
-        const float* sp = a.gn.scale + (int64_t)b * Cin + cg;
-        const float* bp = a.gn.beta + cg;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            q.m[h] = *reinterpret_cast<const float4*>(mp + 4 * h);
-            q.s[h] = *reinterpret_cast<const float4*>(sp + 4 * h);
-            q.b[h] = *reinterpret_cast<const float4*>(bp + 4 * h);
-        }
-    };
-    // The raw pieces RX (parameters Q) of one chunk are normalised into the halo buffer at byte offset HB, stage by stage over
-    // ALL pieces (48 values): a lone wave hides no latency by itself -- piece after piece the dependent unpack -> fma -> exp ->
-    // rcp -> mul chains ran at ~10 cycles per instruction, 48 independent values per stage keep the VALU issuing.  SCALAR
-    // fp32 instructions on purpose (this translation unit is built with -fno-slp-vectorize): the staging now runs beside the
-    // consumers' MFMA stream, where a packed fp32 instruction costs ~20 cycles more than the two scalar ones it replaces
-    // (MI355X_MICROARCH.md; here: 26 k vs ... cycles of staging per tile, tools/pc16_ts.py).
-#define FLOWSE_PC_BURST(RX, HINX, Q, HB)                                                                             \
-    if (GN && !((HINX) >> 31)) {                                                                                     \
-        /* folded affine: y = (x - mean) scale + beta = x sc + sh; SiLU exponent -log2(e) y = x ec + eh */           \
-        float sc[8], sh[8], ec[8], eh[8];                                                                            \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                              \
-            const float mm[4] = {Q.m[h].x, Q.m[h].y, Q.m[h].z, Q.m[h].w}, ss[4] = {Q.s[h].x, Q.s[h].y, Q.s[h].z, Q.s[h].w}; \
-            const float bb[4] = {Q.b[h].x, Q.b[h].y, Q.b[h].z, Q.b[h].w};                                            \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
-                sc[4 * h + e] = ss[e];                                                                               \
-                sh[4 * h + e] = __builtin_fmaf(-mm[e], ss[e], bb[e]);                                                \
-                ec[4 * h + e] = -1.44269504088896341f * sc[4 * h + e];                                               \
-                eh[4 * h + e] = -1.44269504088896341f * sh[4 * h + e];                                               \
-            }                                                                                                        \
-        }                                                                                                            \
-        float v[PC_PIECES][8], z[PC_PIECES][8];                                                                      \
-        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
-            const unsigned wsrc[4] = {RX[q].x, RX[q].y, RX[q].z, RX[q].w};                                           \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) St<T16>::unpack2(wsrc[e], v[q][2 * e], v[q][2 * e + 1]);   \
-        }                                                                                                            \
-        if (GN == 2) {                                                                                               \
-            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
-                z[q][e] = __builtin_fmaf(v[q][e], ec[e], eh[e]);                                                     \
-        }                                                                                                            \
-        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)          \
-            v[q][e] = __builtin_fmaf(v[q][e], sc[e], sh[e]);                                                         \
-        if (GN == 2) {                                                                                               \
-            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
-                z[q][e] = __builtin_amdgcn_exp2f(z[q][e]);                                                           \
-            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
-                z[q][e] += 1.f;                                                                                      \
-            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
-                z[q][e] = __builtin_amdgcn_rcpf(z[q][e]);                                                            \
-            _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e)      \
-                v[q][e] *= z[q][e];                                                                                  \
-        }                                                                                                            \
-        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q) {                                                      \
-            const unsigned keepm = (((HINX) >> q) & 1u) ? 0xffffffffu : 0u;   /* zero padding AFTER the activation */ \
-            u32x4 t;                                                                                                 \
-            t.x = pc_pack2<F16>(v[q][0], v[q][1]) & keepm;                                                           \
-            t.y = pc_pack2<F16>(v[q][2], v[q][3]) & keepm;                                                           \
-            t.z = pc_pack2<F16>(v[q][4], v[q][5]) & keepm;                                                           \
-            t.w = pc_pack2<F16>(v[q][6], v[q][7]) & keepm;                                                           \
-            if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) + hlds[q]) = t;                 \
-        }                                                                                                            \
-    } else {                                                                                                         \
-        _Pragma("unroll") for (int q = 0; q < PC_PIECES; ++q)                                                        \
-            if (q < PC_PIECES - 1 || last_valid) *reinterpret_cast<u32x4*>(Hs + (HB) + hlds[q]) = RX[q];             \
-    }
-
-    // ---- prologue: chunks 0, 1, 2 -> buffers 0, 1, 2; raw pieces of chunks 3 and 4 in flight
+    // ---- prologue: chunk 0 -> buffer 0 (chunks 1 and 2: the consumer waves, above); raw pieces of chunks 3 and 4 in flight
     FLOWSE_PC_HLOAD(ra, hin_a, pa)
+    rq_next();                                             // (chunks 1, 2)
+    rq_next();
     FLOWSE_PC_HLOAD(rb, hin_b, pb)
     FLOWSE_PC_BURST(ra, hin_a, pa, 0)
-    FLOWSE_PC_HLOAD(ra, hin_a, pa)
-    FLOWSE_PC_BURST(rb, hin_b, pb, PC_HBUF_X)
-    FLOWSE_PC_HLOAD(rb, hin_b, pb)
-    FLOWSE_PC_BURST(ra, hin_a, pa, 2 * PC_HBUF_X)
     FLOWSE_PC_HLOAD(ra, hin_a, pa)
     PC_TS_DECL
     PC_TS_START
