@@ -47,6 +47,16 @@
 #define PC_TS_EXIT
 #endif
 
+#ifndef FLOWSE_PC16_STORE_AUX
+// Cache policy of the output stores: 16 = sc1, WRITE-THROUGH.  A plain store leaves its line dirty in the XCD's L2 and what is
+// still dirty when the kernel ends is written back at the kernel boundary with every CU idle (MI355X_MICROARCH.md, row
+// "boundary": + B / 6 TB/s behind B dirty bytes); written through, the bytes leave under the kernel's own compute, and the next
+// kernel reads them from HBM / MALL either way (the XCDs' L2s are not coherent with each other).  A-B (tools/ab.py, bf16,
+// [8,1,256,256]): plain 53.65 k, nt 54.5 k, sc1 55.2 k, sc0 sc1 55.2 k frames/s; -3.1 us per launch.  Only for 16-byte stores
+// (a scalar sc1 store is one fabric write each).  The same policy on the fp32 Winograd kernels' stores measured +-0.0 %.
+#define FLOWSE_PC16_STORE_AUX 16
+#endif
+
 namespace flowse {
 
 namespace {
@@ -175,7 +185,7 @@ __device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2
                     s1[q] += d;
                     s2[q] = __builtin_elementwise_fma(d, d, s2[q]);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, po.rs_out, po.voff, pc_osoff<NJ>(po, t, i, k), 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, po.rs_out, po.voff, pc_osoff<NJ>(po, t, i, k), FLOWSE_PC16_STORE_AUX);
                 if (RES && t == 0 && i == 0)                // round 3's residual into the registers round 0 just read
                     FLOWSE_PC_WBK(0, k) = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
                         po.rs_res, po.voff, pc_osoff<NJ>(po, 1, 1, k), 0));
