@@ -106,10 +106,12 @@ int flowse_model_load_weights(flowse_model* m, const float* blob, int64_t numel)
 
 /* Precision mode (call BEFORE flowse_model_load_weights; a change drops the uploaded weights).
  * 0 (default): every operand, product and accumulation is fp32 (v_mfma_f32_32x32x2_f32), activations fp32.  3x3
- *   convolutions with Cin % 32 == 0 and Cout % 64 == 0 on images the LDS-halo kernel covers are evaluated in the F(4,3)
- *   Winograd form along the filter's vertical axis (half the multiplies; transformed fp32 operands, rounding error ~3x
- *   the direct sum's, 4e-7..2e-6 rel-L2 per layer); FLOWSE_NO_WINOGRAD=1 selects the direct form, whose result is bit
- *   for bit an fmaf chain.
+ *   convolutions with Cin % 32 == 0 and Cout % 64 == 0 on images the LDS-halo kernels cover are evaluated in Winograd
+ *   form on transformed fp32 operands: whole-K launches of >= 128 blocks of 16 x 16 pixels x 64 channels in the
+ *   two-dimensional form F(4,3) vertical x F(2,3) horizontal (conv3x3_w2d_kernel: one third of the multiplies, 3.4e-7 ..
+ *   8.8e-7 rel-L2 per layer against the fp64 convolution), the rest in F(4,3) along the vertical axis only
+ *   (conv3x3_f43_kernel: half the multiplies, 4e-7 .. 2e-6); FLOWSE_W2D=0 keeps everything on the one-dimensional form,
+ *   FLOWSE_NO_WINOGRAD=1 selects the direct form, whose result is bit for bit an fmaf chain.
  * 1 "bf16x3": fp32 activations; the operands of the big 3x3 convs are split x = hi + lo in bf16 and the products
  *   hi*hi + hi*lo + lo*hi accumulated in fp32 (fp32-class accuracy, ~1e-5 end to end).
  * 2 "bf16" (BASELINE config 3) / 3 "fp16" (BASELINE config 5): 16-bit STORAGE modes -- every wide activation tensor
@@ -184,11 +186,13 @@ int flowse_istft_decompress(const void* spec_c64, int B, int T, int Tpad, float 
 /* ---- in-library kernel timing (used by bench.py for the live roofline figure) -------------------------
  * Between _begin and _end every selected launch of this handle is bracketed by HIP events on the launch
  * stream (and the handle launches eagerly instead of replaying its hipGraph).  mode 0: only launches of the dominant
- * kernel -- the 3x3 ResBlock convolutions with fused GroupNorm+SiLU input and Cout > 64 (conv3x3_f43_kernel<2> by
- * default) -- reported under the key "dominant_conv3x3"; mode 1: every launch, keyed by op label.  _end synchronises
+ * kernel -- the 3x3 ResBlock convolutions with fused GroupNorm+SiLU input and Cout > 64 (conv3x3_w2d_kernel<2, .> in
+ * the fp32 mode, conv3x3_pc16_kernel<2, ., .> in the 16-bit storage modes) -- reported under the key
+ * "dominant_conv3x3"; mode 1: every launch, keyed by op label.  _end synchronises
  * on the recorded events and writes a JSON object {label: {"launches", "ms", "flops", "bytes", "issued"}} into `json`:
  * algorithmic flops / bytes of the bracketed launches, and `issued` = the flops the matrix cores execute for them
- * (the F(4,3) Winograd form issues 1/2 of the algorithmic direct-convolution flops).  The extra key "_all_launches"
+ * (1/3 of the algorithmic direct-convolution flops per launch of the two-dimensional Winograd form, 1/2 per launch of
+ * the one-dimensional F(4,3) form, all of them otherwise).  The extra key "_all_launches"
  * totals launches / flops / issued over EVERY launch made between _begin and _end (no timing). */
 int flowse_profile_begin(flowse_model* m, int mode);
 int flowse_profile_end(flowse_model* m, char* json, int cap);
