@@ -14,13 +14,60 @@
 //                     register r of the 32x32 C/D layout holds key (r&3)+8(r>>2) on lanes 0-31 and that key + 4
 //                     on lanes 32-63, which is exactly the K=2 operand pair of v_mfma_f32_32x32x2_f32.
 // Work is tiny (0.04 % of the network FLOPs), so the kernel favours simplicity.
-#include "common.h"
+#include "conv_common.h"
 
 namespace flowse {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int ATT_WAVES = 8;     // key tiles are dealt to 8 waves (L = 256 -> one 32-key tile each)
+constexpr int ATT_SLOTS = 4;     // LDS tiles [32 queries][C + 4] the eight waves' O tiles are merged through
+
+// The eight waves' rescaled O^T tiles -> O[query][channel] / l -> out.  Waves 0-3 write their tile into slot (wave & 3),
+// waves 4-7 add theirs to it, then every thread sums the four slots in a fixed order, normalises and stores (bit-
+// reproducible).  (Rounds 1-4 added the eight tiles one after the other into ONE slot, eight block barriers with a dependent
+// LDS read-modify-write chain each: 12.8 of the kernel's 57 us at L = 256, C = 256 -- s_memrealtime stamps per phase.)
+// Precondition: a block barrier since the last read of the query tile (slot 0 overlays it) and of sm_l.
+template <int NCT, class OT>
+__device__ __forceinline__ void att_merge_store(const f32x16 (&o)[NCT], float f, float l_tot, float* Os, float* sm_l,
+                                                OT* __restrict__ out, int b, int L, int q0) {
+    constexpr int C = 32 * NCT, OROW = C + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    float* slot = Os + (wave & (ATT_SLOTS - 1)) * (32 * OROW);
+#pragma unroll 1
+    for (int round = 0; round < ATT_WAVES / ATT_SLOTS; ++round) {
+        if (wave / ATT_SLOTS == round) {
+#pragma unroll
+            for (int t = 0; t < NCT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4* p = reinterpret_cast<float4*>(slot + li * OROW + t * 32 + 8 * g + 4 * kh);
+                    float4 v = make_float4(o[t][4 * g] * f, o[t][4 * g + 1] * f, o[t][4 * g + 2] * f, o[t][4 * g + 3] * f);
+                    if (round > 0) {
+                        const float4 old = *p;
+                        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                    }
+                    *p = v;
+                }
+        }
+        // wave 0's row of sm_l takes l for every thread below -- in round 1: behind a barrier that every wave passes after its
+        // last read of sm_l (l_tot)
+        if (round == 1 && kh == 0 && wave == 0) sm_l[li] = l_tot;
+        __syncthreads();
+    }
+    for (int i = tid; i < 32 * (C / 4); i += 64 * ATT_WAVES) {
+        const int r = i / (C / 4), c4 = i - r * (C / 4);
+        if (q0 + r >= L) continue;
+        const float inv = 1.f / sm_l[r];
+        const float* p = Os + r * OROW + c4 * 4;
+        const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 32 * OROW);
+        const float4 v2 = *reinterpret_cast<const float4*>(p + 2 * 32 * OROW), v3 = *reinterpret_cast<const float4*>(p + 3 * 32 * OROW);
+        const float4 v = make_float4((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y), (v0.z + v1.z) + (v2.z + v3.z),
+                                     (v0.w + v1.w) + (v2.w + v3.w));
+        St<OT>::st4(out + ((int64_t)b * L + q0 + r) * C + c4 * 4, make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv));
+    }
+}
 
 template <int NCT>   // C = 32 * NCT
 __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const float* __restrict__ qkv, int L,
@@ -28,8 +75,8 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const float* 
     constexpr int C = 32 * NCT;
     constexpr int QROW = C + 4;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Qs = sm;                       // [32][QROW]: query tile, later the merged O tile
-    float* sm_m = sm + 32 * QROW;         // [ATT_WAVES][32] running max per wave
+    float* Qs = sm;                       // [32][QROW]: query tile; later slot 0 of the ATT_SLOTS merge tiles
+    float* sm_m = sm + ATT_SLOTS * 32 * QROW;   // [ATT_WAVES][32] running max per wave
     float* sm_l = sm_m + ATT_WAVES * 32;  // [ATT_WAVES][32] running sum per wave
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -61,28 +108,27 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         const int krow = k0 + li;
-        const bool kok = krow < L;
-        const float* kp = base + (int64_t)(kok ? krow : 0) * rs + C + kh * 4;
+        // (a key row past L reads row 0: its scores are masked to -inf below, its probabilities are exactly 0, so neither the K
+        // nor the V operand needs a select -- a select on a loaded value pins the wait for that load to the spot where it was
+        // issued, which is what had kept every one of these requests from running ahead: PV 31 us, S 10 us of 57)
+        const float* kp = base + (int64_t)(krow < L ? krow : 0) * rs + C + kh * 4;
         const float* qp = Qs + li * QROW + kh * 4;
-        // The loop is one chain of dependent MFMAs, so a load inside it is a full L2 round trip that nothing hides: the key
-        // row runs through a ring of four quads, each requested four iterations (16 MFMAs = 1 024 cycles) ahead of its use.
+        // The loop is one chain of dependent MFMAs, so a load inside it is a full memory round trip that nothing hides, and
+        // q / k / v were written by the previous launch (other XCDs' L2s: the round trip is ~2 us, not an L2 hit): the key
+        // row runs through a ring of AR quads, each requested AR iterations (4 AR MFMAs) ahead of its use.  Round 5: AR 4 ->
+        // 16 (a ring of four left ~1.5 us of every 0.12 us iteration exposed: the S tile took ~45 of the kernel's 60 us).
         constexpr int NQ = C / 8;
-        float4 ak[4];
+        constexpr int AR = NQ < 16 ? NQ : 16;
+        float4 ak[AR];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            ak[u] = u < NQ ? *reinterpret_cast<const float4*>(kp + u * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!kok) ak[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int u = 0; u < AR; ++u) ak[u] = *reinterpret_cast<const float4*>(kp + u * 8);
 #pragma unroll 1
-        for (int g = 0; g < NQ; g += 4) {
+        for (int g = 0; g < NQ; g += AR) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < AR; ++u) {
                 const int j = g + u;
                 const float4 a = ak[u];
-                if (j + 4 < NQ) {
-                    ak[u] = *reinterpret_cast<const float4*>(kp + (j + 4) * 8);
-                    if (!kok) ak[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                if (j + AR < NQ) ak[u] = *reinterpret_cast<const float4*>(kp + (j + AR) * 8);
                 const float4 q = *reinterpret_cast<const float4*>(qp + j * 8);
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q.x, s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q.y, s, 0, 0, 0);
@@ -110,20 +156,25 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const float* 
         psum += __shfl_xor(psum, 32);
         l_run = l_run * alpha + psum;
         m_run = m_new;
-        // ---- O^T = alpha O^T + V^T P^T
-#pragma unroll
-        for (int t = 0; t < NCT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-            float vv[16];                       // the channel tile's 16 V rows, requested together
+        // ---- O^T = alpha O^T + V^T P^T.  A channel tile's 16 V rows are requested together, TWO tiles ahead of their MFMAs
+        // (requested at their use, every tile waited a full memory round trip: 8 x ~2 us).
+        float vv[3][16];
+        auto vload = [&](int t, float (&dst)[16]) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const float v = base[(int64_t)(key < L ? key : 0) * rs + 2 * C + t * 32 + li];
-                vv[r] = key < L ? v : 0.f;
+                dst[r] = base[(int64_t)(key < L ? key : 0) * rs + 2 * C + t * 32 + li];
             }
+        };
+        vload(0, vv[0]);
+        if (NCT > 1) vload(1, vv[1]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[r], s[r], o[t], 0, 0, 0);
+        for (int t = 0; t < NCT; ++t) {
+            if (t + 2 < NCT) vload(t + 2, vv[(t + 2) % 3]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[t % 3][r], s[r], o[t], 0, 0, 0);
         }
     }
     // ---- merge the per-wave states: m = max_w m_w, O = sum_w O_w e^{m_w - m}, l = sum_w l_w e^{m_w - m}
@@ -139,42 +190,14 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const float* 
 #pragma unroll
     for (int w = 0; w < ATT_WAVES; ++w) l_tot += sm_l[w * 32 + li] * expf(sm_m[w * 32 + li] - m_tot);
     const float f = expf(m_run - m_tot);   // 0 for a wave that saw no key tile (m_run = -inf)
-    float* Os = Qs;                        // merged O[query][channel], row stride QROW
-#pragma unroll 1
-    for (int w = 0; w < ATT_WAVES; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int t = 0; t < NCT; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4* p = reinterpret_cast<float4*>(Os + li * QROW + t * 32 + 8 * g + 4 * kh);
-                    float4 v = make_float4(o[t][4 * g] * f, o[t][4 * g + 1] * f, o[t][4 * g + 2] * f,
-                                           o[t][4 * g + 3] * f);
-                    if (w > 0) {
-                        const float4 old = *p;
-                        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
-                    }
-                    *p = v;
-                }
-        }
-        __syncthreads();
-    }
-    if (kh == 0 && wave == 0) sm_l[li] = l_tot;     // wave 0 of sm_l is free now: broadcast 1/l to all threads
-    __syncthreads();
-    for (int i = tid; i < 32 * (C / 4); i += 64 * ATT_WAVES) {
-        const int r = i / (C / 4), c4 = i - r * (C / 4);
-        if (q0 + r >= L) continue;
-        const float inv = 1.f / sm_l[r];
-        const float4 v = *reinterpret_cast<const float4*>(Os + r * QROW + c4 * 4);
-        *reinterpret_cast<float4*>(out + ((int64_t)b * L + q0 + r) * C + c4 * 4) =
-            make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
-    }
+    att_merge_store<NCT, float>(o, f, l_tot, Qs, sm_l, out, b, L, q0);
 }
 
 template <int NCT>
 static int launch_att(const float* qkv, int B, int L, float* out, hipStream_t s) {
     constexpr int C = 32 * NCT;
-    const size_t lds = (32 * (C + 4) + 2 * ATT_WAVES * 32) * sizeof(float);
+    const size_t lds = (ATT_SLOTS * 32 * (C + 4) + 2 * ATT_WAVES * 32) * sizeof(float);
+    if (const int rc = allow_lds<&attention_kernel<NCT>>(lds)) return rc;
     const dim3 grid((L + 31) / 32, B), block(64 * ATT_WAVES);
     hipLaunchKernelGGL(attention_kernel<NCT>, grid, block, lds, s, qkv, L, out, 1.0f / sqrtf((float)C));
     FLOWSE_LAUNCH_CHECK();
@@ -202,8 +225,8 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention16_kernel(const ST* _
     constexpr int QROWB = C * 2 + 16;                   // bytes per staged query row (16 B pad: conflict-free b128 reads)
     constexpr int OROW = C + 4;                         // floats per row of the merged O tile
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    char* Qs = reinterpret_cast<char*>(sm);             // [32][QROWB] 16-bit query tile; later (fp32) the merged O tile
-    float* sm_m = sm + 32 * OROW;                       // [ATT_WAVES][32]
+    char* Qs = reinterpret_cast<char*>(sm);             // [32][QROWB] 16-bit query tile; later (fp32) slot 0 of the merge tiles
+    float* sm_m = sm + ATT_SLOTS * 32 * OROW;           // [ATT_WAVES][32]
     float* sm_l = sm_m + ATT_WAVES * 32;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -233,14 +256,10 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention16_kernel(const ST* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         const int krow = k0 + li;
-        const bool kok = krow < L;
-        const ST* kp = base + (int64_t)(kok ? krow : 0) * rs + C + kh * 8;
+        const ST* kp = base + (int64_t)(krow < L ? krow : 0) * rs + C + kh * 8;
         au32x4 ak[C / 16];
 #pragma unroll
-        for (int j = 0; j < C / 16; ++j) {
-            ak[j] = *reinterpret_cast<const au32x4*>(kp + j * 16);
-            if (!kok) ak[j] = au32x4{0u, 0u, 0u, 0u};
-        }
+        for (int j = 0; j < C / 16; ++j) ak[j] = *reinterpret_cast<const au32x4*>(kp + j * 16);   // (no select: see the fp32 kernel)
 #pragma unroll
         for (int j = 0; j < C / 16; ++j) {
             const au32x4 q = *reinterpret_cast<const au32x4*>(Qs + li * QROWB + (j * 16 + kh * 8) * 2);
@@ -280,25 +299,30 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention16_kernel(const ST* _
             pb[u].w = St<ST>::pack2(s[8 * u + 6], s[8 * u + 7]);
         }
         // ---- O^T = alpha O^T + V^T P^T: per channel tile two MFMAs; A = V[key(u, j, kh)][channel 32 t + li], gathered
+        // from global memory, requested TWO channel tiles ahead of its MFMAs (at its use every tile waited a full round trip)
         const unsigned short* vb = reinterpret_cast<const unsigned short*>(base) + 2 * C + li;
-#pragma unroll
-        for (int t = 0; t < NCT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-            unsigned short vv[16];
+        unsigned short vv[3][16];
+        auto vload = [&](int t, unsigned short (&dst)[16]) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const unsigned short v = vb[(int64_t)(key < L ? key : 0) * rs + t * 32];
-                vv[r] = key < L ? v : (unsigned short)0;
+                dst[r] = vb[(int64_t)(key < L ? key : 0) * rs + t * 32];
             }
+        };
+        vload(0, vv[0]);
+        if (NCT > 1) vload(1, vv[1]);
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+            if (t + 2 < NCT) vload(t + 2, vv[(t + 2) % 3]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 au32x4 va;
-                va.x = (unsigned)vv[8 * u + 0] | ((unsigned)vv[8 * u + 1] << 16);
-                va.y = (unsigned)vv[8 * u + 2] | ((unsigned)vv[8 * u + 3] << 16);
-                va.z = (unsigned)vv[8 * u + 4] | ((unsigned)vv[8 * u + 5] << 16);
-                va.w = (unsigned)vv[8 * u + 6] | ((unsigned)vv[8 * u + 7] << 16);
+                va.x = (unsigned)vv[t % 3][8 * u + 0] | ((unsigned)vv[t % 3][8 * u + 1] << 16);
+                va.y = (unsigned)vv[t % 3][8 * u + 2] | ((unsigned)vv[t % 3][8 * u + 3] << 16);
+                va.z = (unsigned)vv[t % 3][8 * u + 4] | ((unsigned)vv[t % 3][8 * u + 5] << 16);
+                va.w = (unsigned)vv[t % 3][8 * u + 6] | ((unsigned)vv[t % 3][8 * u + 7] << 16);
                 if (F16)
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(af16x8, va), __builtin_bit_cast(af16x8, pb[u]), o[t], 0, 0, 0);
                 else
@@ -319,40 +343,14 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention16_kernel(const ST* _
 #pragma unroll
     for (int w = 0; w < ATT_WAVES; ++w) l_tot += sm_l[w * 32 + li] * expf(sm_m[w * 32 + li] - m_tot);
     const float f = expf(m_run - m_tot);
-    float* Os = sm;                        // merged O[query][channel] fp32, row stride OROW (overlays the query tile)
-#pragma unroll 1
-    for (int w = 0; w < ATT_WAVES; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int t = 0; t < NCT; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4* p = reinterpret_cast<float4*>(Os + li * OROW + t * 32 + 8 * g + 4 * kh);
-                    float4 v = make_float4(o[t][4 * g] * f, o[t][4 * g + 1] * f, o[t][4 * g + 2] * f, o[t][4 * g + 3] * f);
-                    if (w > 0) {
-                        const float4 old = *p;
-                        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
-                    }
-                    *p = v;
-                }
-        }
-        __syncthreads();
-    }
-    if (kh == 0 && wave == 0) sm_l[li] = l_tot;
-    __syncthreads();
-    for (int i = tid; i < 32 * (C / 4); i += 64 * ATT_WAVES) {
-        const int r = i / (C / 4), c4 = i - r * (C / 4);
-        if (q0 + r >= L) continue;
-        const float inv = 1.f / sm_l[r];
-        const float4 v = *reinterpret_cast<const float4*>(Os + r * OROW + c4 * 4);
-        St<ST>::st4(out + ((int64_t)b * L + q0 + r) * C + c4 * 4, make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv));
-    }
+    att_merge_store<NCT, ST>(o, f, l_tot, sm, sm_l, out, b, L, q0);
 }
 
 template <int NCT, class ST>
 static int launch_att16(const void* qkv, int B, int L, void* out, hipStream_t s) {
     constexpr int C = 32 * NCT;
-    const size_t lds = (32 * (C + 4) + 2 * ATT_WAVES * 32) * sizeof(float);      // the fp32 O tile is the larger overlay
+    const size_t lds = (ATT_SLOTS * 32 * (C + 4) + 2 * ATT_WAVES * 32) * sizeof(float);      // the fp32 O tiles are the larger overlay
+    if (const int rc = allow_lds<&attention16_kernel<NCT, ST>>(lds)) return rc;
     const dim3 grid((L + 31) / 32, B), block(64 * ATT_WAVES);
     hipLaunchKernelGGL((attention16_kernel<NCT, ST>), grid, block, lds, s, static_cast<const ST*>(qkv), L, static_cast<ST*>(out),
                        1.0f / sqrtf((float)C));

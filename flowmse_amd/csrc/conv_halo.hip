@@ -302,7 +302,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_head4_kernel(ConvArgs a) {
     // lane = pixel of the wave's 4 x 16 strip: row lane >> 4, column lane & 15 (halo coordinates +1)
     const float* Ap = Hs + ((4 * wave + (lane >> 4)) * 18 + (lane & 15)) * LDS_ROW;
     const float* Bp = Ws + (lane & 3) * 9 * LDS_ROW;
-    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    // two accumulator chains (channels 0, 2 / 1, 3 of a quad): a two-pass MFMA issued straight behind the one it accumulates
+    // onto waits for it (pyramid_conv@256x256: 111 -> 102 us); summed once at the end
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = Cin / KC;
     gload(0);
@@ -319,15 +321,16 @@ __global__ __launch_bounds__(256, 3) void conv3x3_head4_kernel(ConvArgs a) {
                 const float4 av = *reinterpret_cast<const float4*>(At + q * 4);
                 const float4 bv = *reinterpret_cast<const float4*>(Bt + q * 4);
                 acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, bv.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, bv.y, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, bv.y, acc1, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, bv.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, bv.w, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, bv.w, acc1, 0, 0, 0);
             }
         }
         __syncthreads();                                 // everyone has left this chunk's tiles
         lstore();
         __syncthreads();
     }
+    acc += acc1;
     // accumulator register r: pixel (lane & ~3) + r of the strip, channel lane & 3
     const int j = lane & 3;
     const float bj = a.bias ? a.bias[j] : 0.f;
