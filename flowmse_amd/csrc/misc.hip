@@ -73,16 +73,27 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ i
     const int r = blockIdx.x * 4 + wave;
     if (r >= R) return;
     const float* wr = W + (int64_t)r * K;
-    for (int b = 0; b < B; ++b) {
-        const float* x = in + (int64_t)b * K;
-        float acc = 0.f;
-        for (int k = lane; k < K; k += 64) acc = fmaf(wr[k], x[k], acc);
+    // eight samples per pass over the row (one sample per pass re-read the row and waited a memory round trip per sample:
+    // 40 us for the [10 752][512] table at batch 8); per (sample, row) the same fmaf chain and shuffle tree as before
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float acc[8];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) {
-            float v = acc + (bias ? bias[r] : 0.f);
-            if (act) v = silu_f(v);
-            out[(int64_t)b * out_stride + r] = v;
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float w = wr[k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, in[(int64_t)min(b0 + j, B - 1) * K + k], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0 && b0 + j < B) {
+                v += bias ? bias[r] : 0.f;
+                if (act) v = silu_f(v);
+                out[(int64_t)(b0 + j) * out_stride + r] = v;
+            }
         }
     }
 }
