@@ -203,6 +203,12 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(ConvArgs a) {
     }
 }
 
+// (Round 5, measured and removed: a persistent form of this kernel -- a wave walks several items, the finished item leaves
+// through a second accumulator set, or through a wave-private LDS tile as one 16-byte store per k-block step of the next
+// item's loop -- hides the output phase, 9.5 of a block's 38 us by s_memrealtime stamps, completely, and measures EQUAL:
+// 109.3 vs 109.5 TFLOP/s on [8,256,256,256 -> 128], also with the stores removed altogether (113.8).  The K loop of this
+// kernel already keeps the matrix pipes 100 % busy for 27 us of every 38; run back to back the same loop takes 16 % more
+// cycles at a 6 % lower clock -- the launch is bound by what the part grants an MFMA-dense fp32 kernel, not by its schedule.)
 // shapes the streaming kernel takes: fp32 1x1, more than 2048 pixels (below: conv_smallm.hip), whole 256-pixel blocks per
 // sample, 32-aligned input channels, Cout a multiple of 128.  FLOWSE_NO_STREAM1X1=1: the flat kernel of rounds 1-4 (A-B hook)
 static const bool g_no_stream = getenv("FLOWSE_NO_STREAM1X1") != nullptr || getenv("FLOWSE_FORCE_GENERIC_CONV") != nullptr;

@@ -189,7 +189,7 @@ struct Builder {
             int taps, const Tn* res, float scale, bool out_is_res = false, bool cin4 = false,
             const GnBuf* gin = nullptr, bool gin_silu = false, int64_t wq_off = -1, int out_dt = -1,
             SkPartial* defer = nullptr, const SkPartial* extra = nullptr, GnFuse* gnf = nullptr,
-            const ScFold* fold = nullptr) {
+            const ScFold* fold = nullptr, bool no_stats = false) {
         flowse_model* M = m;
         const int C1 = a.C, C2 = b2 ? b2->C : 0, H = a.H, Wd = a.W, Bn = B;
         {   // a deferred reduction leaves no output tensor: decide before anything is allocated
@@ -242,6 +242,7 @@ struct Builder {
                                    conv_supports_w2d(Bn, H, Wd, C1, C2, Cout, taps)) ? w2_it->second : -1;
         if (wino2_off >= 0 && st_nblk > 0) st_nblk = H * Wd / 64;
         if (defer || gnf) st_nblk = 0;                   // no output here / the statistics are finished inside the reduction
+        if (no_stats) st_nblk = 0;                       // nobody normalises this tensor (the shortcut: a residual only)
         if (out_is_res && o.st_nblk > 0) {               // updated in place: the producer's statistics are stale
             arena.release(o.st_off);
             o.st_nblk = 0;
@@ -459,7 +460,7 @@ struct Builder {
         if (!mod.up && !mod.down) {
             if (mod.shortcut && !fold_sc) {
                 xs = conv("conv2_1x1", x1, x2, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f, false, false, nullptr,
-                          false, -1, -1, merge_sc ? &sp : nullptr);
+                          false, -1, -1, merge_sc ? &sp : nullptr, nullptr, nullptr, nullptr, true);
             }
             if (fusable(x1, x2 ? x2->C : 0)) {
                 // Conv_0(act(GroupNorm_0(x))) in one kernel: the normalised tensor never reaches HBM
@@ -480,7 +481,7 @@ struct Builder {
             // the shortcut Conv_2(x) (layerspp.py:268-270)
             if (!fold_sc)
                 xs = conv("conv2_1x1", xr, nullptr, mod.w_c2, mod.w_c2_b, -1, mod.out_ch, 1, nullptr, 1.f, false, false, nullptr,
-                          false, -1, -1, merge_sc ? &sp : nullptr);
+                          false, -1, -1, merge_sc ? &sp : nullptr, nullptr, nullptr, nullptr, true);
             h1 = conv("conv0_3x3", hr, nullptr, mod.w_c0, -1, mod.dense_row0, mod.out_ch, 9, nullptr, 1.f, false, false,
                       nullptr, false, mod.wq_c0, -1, nullptr, nullptr, &gf);
             release(hr);

@@ -81,6 +81,9 @@ STREAM_CASES = [
     (4, 128, 128, 128, 128, 128, True, True, True, 0.70710678),   # per-sample bias and residual through the direct stores
     (1, 256, 256, 128, 0, 128, False, False, False, 1.0),         # one utterance at the top level
     (2, 128, 256, 32, 0, 128, True, False, True, 1.0),            # one chunk (K = 32)
+    # bias-and-scale-only launches (the form the model's shortcuts take: no residual, no statistics), one / two channel blocks
+    (8, 128, 192, 128, 128, 128, True, False, False, 0.70710678),
+    (6, 64, 96, 128, 128, 256, True, False, False, 0.70710678),
 ]
 
 
