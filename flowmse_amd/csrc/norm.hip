@@ -193,8 +193,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const ST* __restrict__ in
     St<OT>::st4(out + pix * C + c, o);
 }
 
-// Small images: finalize and apply in ONE launch.  grid (G, B): the block reduces its group's partials exactly like
-// gn_finalize, then normalises (+ SiLU) the group's HW x cpg elements of cat[in1, in2] into `out`.
+// Small images: finalize and apply in ONE launch.  grid (G, B, Z): the block reduces its group's partials exactly like
+// gn_finalize, then normalises (+ SiLU) its slice z of the group's HW x cpg elements of cat[in1, in2] into `out`.  (Z > 1 for
+// a single utterance: with G x B = 32 blocks the 32 x 32 level took 15.7 us for a 1 MB tensor -- a latency chain per thread on
+// an eighth of the chip; every slice repeats the few-hundred-value reduction, which is cheaper than a second launch.)
 template <class ST, class OT>
 __global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const ST* __restrict__ in1, const float* __restrict__ p1,
                                                                int nblk1, int ppb1, int C1,
@@ -207,16 +209,16 @@ __global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const ST* __rest
     const int C = C1 + C2, cpg = C / G;
     float muf, rstd;
     gn_group_stats(p1, nblk1, ppb1, C1, p2, nblk2, ppb2, C2, HW, G, eps, g, b, muf, rstd);
-    const int n = HW * cpg;
+    const int px0 = (int)((int64_t)HW * blockIdx.z / gridDim.z), px1 = (int)((int64_t)HW * (blockIdx.z + 1) / gridDim.z);
     // groups of whole channel quads that lie in ONE source tensor (every shape of the released net): 16- or 8-byte accesses, a
     // pixel's quads in neighbouring lanes -- the element-by-element loop below took 11 us for a [8, 16, 16, 256] tensor
     if ((cpg & 3) == 0 && (C1 & 3) == 0 && (C2 & 3) == 0 && ((g + 1) * cpg <= C1 || g * cpg >= C1)) {
-        const int qpp = cpg >> 2, nq = HW * qpp;
+        const int qpp = cpg >> 2, nq = px1 * qpp;
         const bool first = (g + 1) * cpg <= C1;
         const ST* src = first ? in1 : in2;
         const int Cs = first ? C1 : C2, cs0 = first ? g * cpg : g * cpg - C1;
         const float sc = rstd;
-        for (int i = threadIdx.x; i < nq; i += 256) {
+        for (int i = px0 * qpp + threadIdx.x; i < nq; i += 256) {
             const int pix = i / qpp, j = i - pix * qpp;
             const int64_t px = (int64_t)b * HW + pix;
             const float4 x = St<ST>::ld4(src + px * Cs + cs0 + 4 * j);
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const ST* __rest
         }
         return;
     }
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = px0 * cpg + threadIdx.x; i < px1 * cpg; i += 256) {
         const int pix = i / cpg, c = g * cpg + (i - pix * cpg);
         const int64_t px = (int64_t)b * HW + pix;
         const float x = c < C1 ? St<ST>::ld1(in1 + px * C1 + c) : St<ST>::ld1(in2 + px * C2 + (c - C1));
@@ -276,12 +278,15 @@ template <class ST>
 static void launch_gfa(const void* in1, const float* partial1, int nblk1, int ppb1, int C1, const void* in2,
                        const float* partial2, int nblk2, int ppb2, int C2, int B, int HW, int G, const float* gamma,
                        const float* beta, float eps, int silu, void* out, int out_dt, hipStream_t s) {
+    // pixel slices per (group, sample): up to one block per CU, at least 128 pixels each
+    int Z = 1;
+    while (Z < 8 && G * B * Z * 2 <= 256 && HW / (Z * 2) >= 128) Z *= 2;
     if (out_dt == DT_F32)
-        hipLaunchKernelGGL((gn_finalize_apply_kernel<ST, float>), dim3(G, B), dim3(256), 0, s, static_cast<const ST*>(in1),
+        hipLaunchKernelGGL((gn_finalize_apply_kernel<ST, float>), dim3(G, B, Z), dim3(256), 0, s, static_cast<const ST*>(in1),
                            partial1, nblk1, ppb1, C1, static_cast<const ST*>(in2), partial2, nblk2, ppb2, C2, HW, G, gamma,
                            beta, eps, silu, static_cast<float*>(out));
     else
-        hipLaunchKernelGGL((gn_finalize_apply_kernel<ST, ST>), dim3(G, B), dim3(256), 0, s, static_cast<const ST*>(in1),
+        hipLaunchKernelGGL((gn_finalize_apply_kernel<ST, ST>), dim3(G, B, Z), dim3(256), 0, s, static_cast<const ST*>(in1),
                            partial1, nblk1, ppb1, C1, static_cast<const ST*>(in2), partial2, nblk2, ppb2, C2, HW, G, gamma,
                            beta, eps, silu, static_cast<ST*>(out));
 }
