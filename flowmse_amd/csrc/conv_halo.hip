@@ -426,7 +426,9 @@ __global__ __launch_bounds__(256) void conv_cin4_kernel(ConvArgs a, int Q) {
 // Combine (conv1x1 4 -> C plus the in-place residual, layerspp.py:55-59) WITH the GroupNorm partial statistics of what it
 // writes: a block owns PB = min(128, H W) consecutive pixels of one sample (its threads = Cout/4 channel quads x 256/(Cout/4)
 // pixel rows walk them), accumulates pivoted (mean, M2) per thread and merges the pixel rows through LDS.  Saves the
-// gn_stats launch that used to re-read the tensor right after this kernel wrote it.
+// gn_stats launch that used to re-read the tensor right after this kernel wrote it.  OT = the storage type of res / out (the
+// 4-channel input is always fp32); the statistics are those of the values as stored (rounded to OT).
+template <class OT>
 __global__ __launch_bounds__(256) void conv_cin4_stats_kernel(ConvArgs a, int Q, int PB) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [Cout][4] weights, then [R][Q][8] statistics scratch
     const int tid = threadIdx.x;
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(256) void conv_cin4_stats_kernel(ConvArgs a, int Q,
             const int p = p0 + u * R;
             const int64_t m = m0 + (p < PB ? p : pr);
             xv[u] = *reinterpret_cast<const float4*>(a.in1 + m * 4);
-            rv[u] = a.res ? *reinterpret_cast<const float4*>(a.res + m * a.Cout + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rv[u] = a.res ? St<OT>::ld4(reinterpret_cast<const OT*>(a.res) + m * a.Cout + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -479,8 +481,8 @@ __global__ __launch_bounds__(256) void conv_cin4_stats_kernel(ConvArgs a, int Q,
             float4 v = make_float4(o[0] + bq.x, o[1] + bq.y, o[2] + bq.z, o[3] + bq.w);
             if (a.res) { v.x += rv[u].x; v.y += rv[u].y; v.z += rv[u].z; v.w += rv[u].w; }
             v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
-            *reinterpret_cast<float4*>(a.out + (m0 + p) * a.Cout + cq * 4) = v;
-            st.add(v);
+            St<OT>::st4(reinterpret_cast<OT*>(a.out) + (m0 + p) * a.Cout + cq * 4, v);
+            st.add(St<OT>::rnd4(v));
         }
     }
     st.finish(red + (pr * Q + cq) * 8);
@@ -576,15 +578,15 @@ int launch_conv_cin4(const ConvArgs& a, hipStream_t s) {
         (size_t)a.Cout * a.taps * 16 > 64 * 1024) {
         return launch_conv(a, s);      // generic path handles any shape
     }
-    if (a.stats) {                                       // Combine with fused statistics (fp32, 1x1)
+    if (a.stats) {                                       // Combine with fused statistics (1x1)
         const int nblk = conv_cin4_stats_blocks(a.B, a.H, a.W, a.Cout);
-        if (a.taps != 1 || a.out_dt != DT_F32 || nblk == 0 || a.stats_nblk != nblk) {
-            set_error("conv_cin4: fused statistics need a 1x1 fp32 conv on whole statistics blocks (stats_nblk=%d)", a.stats_nblk);
+        if (a.taps != 1 || a.in_dt != DT_F32 || nblk == 0 || a.stats_nblk != nblk) {
+            set_error("conv_cin4: fused statistics need a 1x1 conv of an fp32 input on whole statistics blocks (stats_nblk=%d)", a.stats_nblk);
             return ERR_ARG;
         }
         const int PB = a.H * a.W / nblk;
         const size_t lds_s = (size_t)a.Cout * 16 + (size_t)256 * 8 * sizeof(float);
-        hipLaunchKernelGGL(conv_cin4_stats_kernel, dim3((unsigned)((int64_t)a.B * nblk)), dim3(256), lds_s, s, a, Q, PB);
+        FLOWSE_DT_SWITCH(a.out_dt, OT, hipLaunchKernelGGL(conv_cin4_stats_kernel<OT>, dim3((unsigned)((int64_t)a.B * nblk)), dim3(256), lds_s, s, a, Q, PB));
         FLOWSE_LAUNCH_CHECK();
         return OK;
     }

@@ -221,8 +221,8 @@ struct Builder {
                                                                                  : conv16_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps))
                              : conv_fused_stats_blocks(Bn, H, Wd, C1 + C2, Cout, taps);
         if (cin4 && !out_is_res && C1 == 4 && !has2 && conv_cin4_uses_mfma(Bn, H, Wd, Cout, taps)) st_nblk = H * Wd / 128;
-        // Combine (conv1x1 4 -> C, in place on `res`, fp32): the kernel leaves the statistics of the updated tensor
-        if (cin4 && out_is_res && taps == 1 && C1 == 4 && !has2 && idt == DT_F32 && odt == DT_F32 && Cout >= 16)
+        // Combine (conv1x1 4 -> C, in place on `res`, any storage type): the kernel leaves the statistics of the updated tensor
+        if (cin4 && out_is_res && taps == 1 && C1 == 4 && !has2 && idt == DT_F32 && Cout >= 16)
             st_nblk = conv_cin4_stats_blocks(Bn, H, Wd, Cout);
         // conv_ksplit / conv_fused_stats_blocks judge the small-M kernel by the TOTAL channel count; a concat whose parts are
         // not 32-aligned (not in the released net) runs the unsplit flat kernel instead: its statistics geometry applies
