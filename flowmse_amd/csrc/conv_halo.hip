@@ -344,17 +344,172 @@ __global__ __launch_bounds__(256, 3) void conv3x3_head4_kernel(ConvArgs a) {
     }
 }
 
+// The same heads on 16-bit storage (BASELINE configs 2 / 4).  Rounds 2-4 widened the 16-bit input to fp32 and ran the fp32
+// kernel above: half the bytes, the same 288 v_mfma_f32_4x4x1 per wave and chunk -- the same time as in fp32 (123 us at
+// [8,256,256,128], 1.2 TB/s: matrix-issue bound, 2.6 % of config[4]).  Here the halo and the weights sit in LDS in the storage
+// type (GroupNorm + SiLU in fp32 on the way in, ONE rounding, as for every other 16-bit conv operand) and one
+// v_mfma_f32_4x4x4 takes four channels of a pixel at once: 72 matrix instructions per wave and chunk.  A lane's A operand =
+// 4 consecutive channels of its pixel (8 bytes), B = the same 4 channels of weight row lane & 3; accumulator layout as above.
+// Staging: 16-byte pieces (8 channels of a halo pixel), all requested before the first is used.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int H16_ROWB = 72;                         // bytes per halo pixel / weight row: 32 x 16 bit + 8 pad (conflict-free b64 reads)
+
+template <int GN, class ST>
+__global__ __launch_bounds__(256, 3) void conv3x3_head4_16_kernel(ConvArgs a) {
+    constexpr bool F16 = St<ST>::dt == DT_F16;
+    constexpr int HPIX = 18 * 18;
+    constexpr int PIECES = (HPIX * 4 + 255) / 256;       // 16-byte pieces per thread and chunk: 6 (the last one for 16 threads)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Hs = reinterpret_cast<char*>(smem);            // [HPIX][H16_ROWB]
+    char* Ws = Hs + HPIX * H16_ROWB;                     // [4][9][H16_ROWB]
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W;
+    const int Cin = a.C1;
+    const int tiles_x = W >> 4, tiles_img = tiles_x * (H >> 4);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bid / tiles_img, tt = bid - b * tiles_img;
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const int m_tl = (b * H + y0) * W + x0;
+
+    const int oct = tid & 3, hp0 = tid >> 2;             // this thread's 8-channel group; halo pixels hp0 + 64 q
+    unsigned hvo[PIECES];
+    unsigned hin = 0;
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const int hr = hp0 + 64 * q;
+        const int hy = hr / 18, hx = hr - hy * 18;
+        const bool in = hr < HPIX && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+        hvo[q] = in ? (unsigned)((hy * W + hx) * Cin + oct * 8) * 2u : OOB;
+        hin |= in ? (1u << q) : 0u;
+    }
+    const int64_t wbase = (int64_t)m_tl - W - 1;
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<ST*>(reinterpret_cast<const ST*>(a.in1) + wbase * Cin), 0, (17 * W + 18) * Cin * 2, 0x00020000);
+
+    u32x4 rh[PIECES];
+    float4 g_mu[2], g_sc[2], g_be[2], rw0, rw1;
+    auto gload = [&](int chunk) {
+        const unsigned soff = (unsigned)(chunk * KC) * 2u;
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) rh[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc1, hvo[q], soff, 0);
+        if (GN) {
+            const int cg = chunk * KC + oct * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                g_mu[h] = *reinterpret_cast<const float4*>(a.gn.mean + (int64_t)b * Cin + cg + 4 * h);
+                g_sc[h] = *reinterpret_cast<const float4*>(a.gn.scale + (int64_t)b * Cin + cg + 4 * h);
+                g_be[h] = *reinterpret_cast<const float4*>(a.gn.beta + cg + 4 * h);
+            }
+        }
+        // weights of this chunk (fp32 [4][9][Cin]): 4 x 9 rows of 8 float4 = 288 float4, thread t takes t and (t < 32) t + 256
+        rw0 = *reinterpret_cast<const float4*>(a.w + (int64_t)(tid >> 3) * Cin + chunk * KC + (tid & 7) * 4);
+        if (tid < 32) rw1 = *reinterpret_cast<const float4*>(a.w + (int64_t)(32 + (tid >> 3)) * Cin + chunk * KC + (tid & 7) * 4);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            const int hr = hp0 + 64 * q;
+            u32x4 o = rh[q];
+            if (GN) {
+                const unsigned wsrc[4] = {rh[q].x, rh[q].y, rh[q].z, rh[q].w};
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) St<ST>::unpack2(wsrc[e], v[2 * e], v[2 * e + 1]);
+                const float mu[8] = {g_mu[0].x, g_mu[0].y, g_mu[0].z, g_mu[0].w, g_mu[1].x, g_mu[1].y, g_mu[1].z, g_mu[1].w};
+                const float sc[8] = {g_sc[0].x, g_sc[0].y, g_sc[0].z, g_sc[0].w, g_sc[1].x, g_sc[1].y, g_sc[1].z, g_sc[1].w};
+                const float be[8] = {g_be[0].x, g_be[0].y, g_be[0].z, g_be[0].w, g_be[1].x, g_be[1].y, g_be[1].z, g_be[1].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = fmaf(v[e] - mu[e], sc[e], be[e]);
+                    if (GN == 2) y *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * y));
+                    v[e] = y;
+                }
+                const unsigned keep = ((hin >> q) & 1u) ? 0xffffffffu : 0u;      // zero padding AFTER the activation
+                o.x = St<ST>::pack2(v[0], v[1]) & keep; o.y = St<ST>::pack2(v[2], v[3]) & keep;
+                o.z = St<ST>::pack2(v[4], v[5]) & keep; o.w = St<ST>::pack2(v[6], v[7]) & keep;
+            }
+            if (hr < HPIX) {                                 // (rows are 8-byte aligned: two b64 halves)
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2*>(Hs + hr * H16_ROWB + oct * 16) = u32x2{o.x, o.y};
+                *reinterpret_cast<u32x2*>(Hs + hr * H16_ROWB + oct * 16 + 8) = u32x2{o.z, o.w};
+            }
+        }
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(Ws + (tid >> 3) * H16_ROWB + (tid & 7) * 8) = u32x2{St<ST>::pack2(rw0.x, rw0.y), St<ST>::pack2(rw0.z, rw0.w)};
+        if (tid < 32)
+            *reinterpret_cast<u32x2*>(Ws + (32 + (tid >> 3)) * H16_ROWB + (tid & 7) * 8) = u32x2{St<ST>::pack2(rw1.x, rw1.y), St<ST>::pack2(rw1.z, rw1.w)};
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const char* Ap = Hs + ((4 * wave + (lane >> 4)) * 18 + (lane & 15)) * H16_ROWB;
+    const char* Bp = Ws + (lane & 3) * 9 * H16_ROWB;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = Cin / KC;
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        gload(min(chunk + 1, nchunks - 1));              // next chunk into registers under this chunk's MFMAs
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const char* At = Ap + ((tap / 3) * 18 + (tap % 3)) * H16_ROWB;
+            const char* Bt = Bp + tap * H16_ROWB;
+#pragma unroll
+            for (int q = 0; q < KC / 4; ++q) {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 av = *reinterpret_cast<const u32x2*>(At + q * 8);
+                const u32x2 bv = *reinterpret_cast<const u32x2*>(Bt + q * 8);
+                f32x4v& ac = (q & 1) ? acc1 : acc;
+                if (F16) ac = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, av), __builtin_bit_cast(h16x4, bv), ac, 0, 0, 0);
+                else ac = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, av), __builtin_bit_cast(s16x4, bv), ac, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                 // everyone has left this chunk's tiles
+        lstore();
+        __syncthreads();
+    }
+    acc += acc1;
+    // accumulator register r: pixel (lane & ~3) + r of the strip, channel lane & 3
+    const int j = lane & 3;
+    const float bj = a.bias ? a.bias[j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int p = (lane & ~3) + r;
+        const int64_t m = (int64_t)m_tl + (4 * wave + (p >> 4)) * W + (p & 15);
+        float v = acc[r] + bj;
+        if (a.res) v += a.res[m * 4 + j];
+        a.out[m * 4 + j] = v * a.scale;
+    }
+}
+
 bool conv_supports_head4(int B, int H, int W, int C1, int C2, int Cout, int taps) {
     return !conv_force_generic() && taps == 9 && Cout == 4 && C2 == 0 && (C1 % KC) == 0 && !(H & 15) && !(W & 15) &&
            (int64_t)B * (H >> 4) * (W >> 4) >= 64 && (int64_t)(17 * W + 18) * C1 * 4 < (1LL << 31);
 }
 
+// FLOWSE_HEAD4_FP32=1: the 16-bit modes widen the heads' input and run the fp32 kernel, as in rounds 2-4 (A-B hook)
+static const bool g_head4_fp32 = getenv("FLOWSE_HEAD4_FP32") != nullptr;
 int launch_head4(const ConvArgs& a, hipStream_t s) {
     const int grid = a.B * (a.H >> 4) * (a.W >> 4);
     const size_t lds = (size_t)(18 * 18 + 36) * LDS_ROW * sizeof(float);
     if (a.out_dt != DT_F32) {
         set_error("head4: the 4-channel output is fp32");
         return ERR_ARG;
+    }
+    if (a.in_dt != DT_F32 && !g_head4_fp32) {            // 16-bit storage: 16-bit operands on v_mfma_f32_4x4x4
+        const size_t lds16 = (size_t)(18 * 18 + 36) * H16_ROWB;
+        const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;
+#define FLOWSE_H16(GNF)                                                                                                     \
+    if (a.in_dt == DT_BF16) hipLaunchKernelGGL((conv3x3_head4_16_kernel<GNF, bf16_t>), dim3(grid), dim3(256), lds16, s, a); \
+    else hipLaunchKernelGGL((conv3x3_head4_16_kernel<GNF, f16_t>), dim3(grid), dim3(256), lds16, s, a);
+        if (gn == 2) { FLOWSE_H16(2) } else if (gn == 1) { FLOWSE_H16(1) } else { FLOWSE_H16(0) }
+#undef FLOWSE_H16
+        FLOWSE_LAUNCH_CHECK();
+        return OK;
     }
     if (a.gn.mean && a.gn_silu) {
         FLOWSE_DT_SWITCH(a.in_dt, ST, hipLaunchKernelGGL((conv3x3_head4_kernel<2, ST>), dim3(grid), dim3(256), lds, s, a));

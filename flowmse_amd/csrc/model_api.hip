@@ -960,7 +960,10 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t M = (int64_t)B * H * W, C = C1 + C2;
     const bool halo = conv16_uses_halo(B, H, W, C1, C2, Cout, taps);
-    const int ks = halo ? 1 : conv16_ksplit(B, H, W, (int)C, Cout, taps);
+    // the progressive-output heads (C -> 4, ncsnpp.py:345-366): 16-bit input, fp32 residual (the pyramid) and fp32 output, as
+    // in the model -- conv3x3_head4_16_kernel
+    const bool head = Cout == 4 && taps == 9 && !in2 && conv_supports_head4(B, H, W, C1, 0, Cout, taps);
+    const int ks = (halo || head) ? 1 : conv16_ksplit(B, H, W, (int)C, Cout, taps);
     const int64_t nw = ((int64_t)Cout * taps * C + 3) & ~(int64_t)3;
     // the same 256-byte round-up per sub-buffer as take() below, upper bound over the optional ones
     auto up = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
@@ -970,7 +973,7 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
         set_error("flowse_op_conv2d_16: scratch needs %lld bytes", (long long)need);
         return ERR_ARG;
     }
-    if (gn_mean && !halo) {
+    if (gn_mean && !halo && !head) {
         set_error("flowse_op_conv2d_16: fused GroupNorm input only on LDS-halo shapes");
         return ERR_SHAPE;
     }
@@ -1007,8 +1010,13 @@ int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, cons
         c.gn = GnParams{gn_mean, gn_scale, gn_beta};
         c.gn_silu = silu;
     }
+    if (head) {
+        c.res = res;
+        c.out = out;
+        c.out_dt = DT_F32;
+    }
     rc = launch_conv(c, s);
-    if (rc != OK) return rc;
+    if (rc != OK || head) return rc;
     return launch_convert(o16, dt, out, DT_F32, M * Cout, s);
 }
 

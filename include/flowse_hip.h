@@ -224,7 +224,9 @@ int64_t flowse_op_conv2d_scratch_floats(int B, int H, int W, int Cin, int Cout, 
  * Optional fused GroupNorm(+SiLU) of the input from per-(sample, channel) gn_mean / gn_scale [B][C1+C2] and gn_beta
  * [C1+C2] (LDS-halo shapes only).  `scratch`: device memory; sufficient for every shape: 2*(in + 2*w + res + out
  * elements) + 4*ksplit*out elements + 4 KB bytes (each of the up to seven sub-buffers is rounded up to 256 bytes; the
- * error message of a too-small call states the exact byte count). */
+ * error message of a too-small call states the exact byte count).  Cout == 4 with taps == 9 on >= 64 tiles of
+ * 16 x 16 pixels is the progressive-output head (ncsnpp.py:345-366): 16-bit input, but `res` (the pyramid) and `out` stay fp32
+ * as in the model (conv3x3_head4_16_kernel; fused GroupNorm input allowed). */
 int flowse_op_conv2d_16(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
                         const float* res, const float* gn_mean, const float* gn_scale, const float* gn_beta, int silu,
                         float* out, int B, int H, int W, int Cout, int taps, float scale, int dt, void* scratch,

@@ -459,12 +459,13 @@ def _conv16(x, w, dt, bias=None, x2=None, res=None, gn=None, scale=1.0):
 
 @pytest.mark.parametrize("dt,bound", [(1, 4e-3), (2, 5e-4)])
 @pytest.mark.parametrize("case", ["halo", "halo_gn_concat", "halo_32ch", "flat_small_splitk", "flat_1x1_concat", "flat_w8",
-                                  "pc", "pc_gn_concat", "pc_gn_256out", "pc_ragged_items", "pc_64items"])
+                                  "pc", "pc_gn_concat", "pc_gn_256out", "pc_ragged_items", "pc_64items", "head4_gn", "head4_plain"])
 def test_conv2d_16bit_storage(case, dt, bound):
     """pc*: >= 64 (16 x 16 pixel tile, 128-channel block) items -> the persistent producer / consumer kernel
     (conv3x3_pc16_kernel); pc_64items: its smallest launch (64 blocks of one tile); pc_ragged_items: an item count that is no
     multiple of the 256 blocks (blocks with 1 and 2 tiles, tiles of several samples and both channel blocks in one block's
-    stream).  halo*: image heights that are multiples of 8 but not of 16 -> the per-tap kernel (conv3x3_halo_bf16_kernel),
+    stream).  head4*: the progressive-output heads C -> 4 (conv3x3_head4_16_kernel: 16-bit operands on v_mfma_f32_4x4x4, fp32
+    residual and output).  halo*: image heights that are multiples of 8 but not of 16 -> the per-tap kernel (conv3x3_halo_bf16_kernel),
     which no power-of-two image reaches in the storage modes any more."""
     g = torch.Generator().manual_seed(3)
     shapes = {"halo": (6, 128, 0, 128, 24, 128, 3), "halo_gn_concat": (6, 128, 128, 128, 24, 128, 3),
@@ -472,7 +473,8 @@ def test_conv2d_16bit_storage(case, dt, bound):
               "pc_64items": (2, 128, 0, 128, 64, 128, 3),
               "flat_1x1_concat": (2, 256, 128, 128, 32, 64, 1), "flat_w8": (3, 256, 0, 256, 8, 8, 3),
               "pc": (1, 128, 0, 128, 256, 256, 3), "pc_gn_concat": (4, 64, 32, 128, 128, 128, 3),
-              "pc_gn_256out": (2, 64, 0, 256, 128, 128, 3), "pc_ragged_items": (3, 32, 0, 256, 112, 128, 3)}
+              "pc_gn_256out": (2, 64, 0, 256, 128, 128, 3), "pc_ragged_items": (3, 32, 0, 256, 112, 128, 3),
+              "head4_gn": (4, 128, 0, 4, 64, 64, 3), "head4_plain": (4, 64, 0, 4, 64, 64, 3)}
     B, C1, C2, Cout, H, W, k = shapes[case]
     C = C1 + C2
     x = torch.randn(B, C, H, W, generator=g)
@@ -480,7 +482,7 @@ def test_conv2d_16bit_storage(case, dt, bound):
     bias = torch.randn(Cout, generator=g)
     res = torch.randn(B, Cout, H, W, generator=g)
     gn, xin = None, x
-    if case in ("halo_gn_concat", "pc_gn_concat", "pc_gn_256out"):
+    if case in ("halo_gn_concat", "pc_gn_concat", "pc_gn_256out", "head4_gn"):
         mean = 0.2 * torch.randn(B, C, generator=g)
         scl = 1 + 0.2 * torch.randn(B, C, generator=g)
         beta = 0.2 * torch.randn(C, generator=g)
