@@ -696,6 +696,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_cin4_mfma_kernel(ConvArgs a) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    if constexpr (sizeof(OT) == 2) {
+        // 16-bit storage modes: the same K = 36 (+ 12 zero) as THREE v_mfma_f32_32x32x16 per channel tile instead of twenty
+        // 32x32x2 -- in fp32 the matrix instructions of this layer took longer than the HBM write of its output (105 us for
+        // 134 MB at [8,256,256]).  Lane half kh of MFMA m supplies k = 16 m + 8 kh .. + 7 = taps 4 m + 2 kh and 4 m + 2 kh + 1
+        // (four channels each), i.e. the float4 pairs already loaded, rounded once to the storage type like every other
+        // operand of these modes; the weights likewise.
+        constexpr bool F16 = St<OT>::dt == DT_F16;
+        typedef _Float16 hx8 __attribute__((ext_vector_type(8)));
+        auto pack8 = [](const float4& lo, const float4& hi) {
+            u32x4 r;
+            r.x = St<OT>::pack2(lo.x, lo.y); r.y = St<OT>::pack2(lo.z, lo.w);
+            r.z = St<OT>::pack2(hi.x, hi.y); r.w = St<OT>::pack2(hi.z, hi.w);
+            return r;
+        };
+        // (the fp32 form's af[] holds the taps of parity kh only; here a lane needs taps 4 m + 2 kh and 4 m + 2 kh + 1)
+        float4 at[3][2];
+#pragma unroll
+        for (int mq = 0; mq < 3; ++mq)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const int t = 4 * mq + 2 * kh + sl;
+                const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+                const bool ok = t < 9 && m < M && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+                const float4 v = *reinterpret_cast<const float4*>(a.in1 + (int64_t)(ok ? m + dy * W + dx : 0) * 4);
+                at[mq][sl] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = j * 32 + li;
+#pragma unroll
+            for (int mq = 0; mq < 3; ++mq) {
+                float4 wv[2];
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const int t = 4 * mq + 2 * kh + sl;
+                    wv[sl] = t < 9 ? *reinterpret_cast<const float4*>(a.w + ((int64_t)n * 9 + t) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                const u32x4 av = pack8(at[mq][0], at[mq][1]), bv = pack8(wv[0], wv[1]);
+                if (F16) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hx8, av), __builtin_bit_cast(hx8, bv), acc[0][j], 0, 0, 0);
+                else acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[0][j], 0, 0, 0);
+            }
+        }
+        conv_epilogue<4, 1, 1, 4, OT>(a, acc, smem, m0, 0, M, HW, 0);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = j * 32 + li;                       // B row = output channel (Cout == 128)
