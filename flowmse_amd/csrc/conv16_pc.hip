@@ -54,6 +54,8 @@
 // kernel reads them from HBM / MALL either way (the XCDs' L2s are not coherent with each other).  A-B (tools/ab.py, bf16,
 // [8,1,256,256]): plain 53.65 k, nt 54.5 k, sc1 55.2 k, sc0 sc1 55.2 k frames/s; -3.1 us per launch.  Only for 16-byte stores
 // (a scalar sc1 store is one fabric write each).  The same policy on the fp32 Winograd kernels' stores measured +-0.0 %.
+// Loads stay on the default policy: `nt` on the raw halo pieces measured -5 % (the halo overlap and the second channel block
+// live on L2 hits), `nt` on the residual loads +-0.0 %.
 #define FLOWSE_PC16_STORE_AUX 16
 #endif
 
