@@ -65,13 +65,14 @@ namespace {
 constexpr int PC_ROWB = 80;                        // bytes per halo pixel / weight row: 32 x 16 bit + 16 pad (conflict-free b128 reads)
 constexpr int PC_HPITCH = 18 * PC_ROWB + 96;       // halo image row: 1536 B = 0 mod 256
 constexpr int PC_HBUF_X = 18 * PC_HPITCH;            // one halo buffer: 18 rows = 27 KB
-constexpr int PC_NHBUF = 4;                        // halo buffers: the staging runs up to three chunks ahead of the MFMAs
+constexpr int PC_NHBUF = 3;                        // halo buffers: the staging runs two chunks ahead of the MFMAs
 constexpr int PCF_STEP = 2 * 64 * 16;                // fragment-order weights: bytes of one (32-channel block, chunk, tap) = 2 halves x 1 KB
 constexpr int PCF_CHUNK = 9 * PCF_STEP;
-constexpr int PC_RED = 2 * 2 * 128 * 2 * 4;        // statistics scratch of the output stage: [2 waves][2 sub-tiles][128 ch][mean, M2]
-constexpr int PC_TSCR = 4 * 32 * 68 * 4;             // the consumers' transposition tiles (pc16_out_wide)
-constexpr int PC_LDS = PC_NHBUF * PC_HBUF_X + PC_RED + PC_TSCR;
+constexpr int PC_RED = 2 * 4 * 64 * 2 * 4;         // statistics scratch of the drain: [2 strips][4 producer waves][64 channel pairs][mean, M2]
 constexpr int PC_PIECES = 6;                       // 16-byte halo pieces per producer thread and chunk (324 x 4 / 256)
+// hand-off tile of a finished (16 x 16 pixel, 64 NJ channel) item: [256 pixels][64 NJ channels] in the storage type, + 16 B per pixel
+constexpr int pc_opitch(int nj) { return 128 * nj + 16; }
+constexpr int pc_lds(int nj) { return PC_NHBUF * PC_HBUF_X + PC_RED + 256 * pc_opitch(nj); }
 
 // position of one (tile, channel block) work item
 struct PcItem {
@@ -79,160 +80,78 @@ struct PcItem {
 };
 }  // namespace
 
-// ---- output stage of one consumer wave: its 4 x (32 pixels x 64 channels) of accumulators (sub-tile t, row pair i, both
-// channel tiles j) leave through a WAVE-PRIVATE fp32 LDS tile [32 px][64 ch] so that every global access is 16 bytes -- a
-// lane ends up with 8 consecutive channels of one pixel (dword stores straight from the accumulator layout were store-issue
-// bound at ~7 B / cycle / CU).  LDS traffic per lane and tile: 128 ds_write_b32 + 32 ds_read_b128, in-order per wave: no
-// barrier.  Bias / per-sample bias / residual / scale, ONE rounding to the storage type, and the GroupNorm partial
-// statistics (mean, M2 per channel and 8 x 16 statistics tile) of exactly what was stored: per lane over its 8 pixels of a
-// sub-tile (pivoted), equal-count Chan merges over the 8 lanes that share a channel octet (64 pixels), then with the wave
-// that holds the other 64 pixels through `red` ([2][2][128][2] floats) after ONE block barrier -- which the producers match.
+// ---- hand-off of a finished tile (round 6).  The MFMAs run TRANSPOSED (A = weight fragment, B = pixel fragment), so a
+// lane of a consumer wave holds, per 32 x 32 accumulator tile, four runs of four CONSECUTIVE output channels of ONE pixel
+// (register r: channel (r & 3) + 8 (r >> 2) + 4 kh, pixel li).  The accumulators start at bias + per-sample bias + shortcut
+// bias (pc_init_acc), so the consumers' whole output stage is: [+ residual] * scale, ONE rounding to the storage type, one
+// ds_write_b64 per run into the hand-off tile O[pixel][channel] -- ~160 instructions per wave and tile where the round-4/5
+// stage (fp32 transposition through wave-private LDS tiles, bias / scale / statistics in the MFMA waves, a block barrier
+// for the statistics exchange) took ~1 600 and a fifth of a four-chunk tile's time with the matrix pipe idle.  The
+// PRODUCER waves drain O during the next tile's first two chunk intervals: 16-byte pieces LDS -> global (write-through),
+// and the GroupNorm partial statistics of exactly what is stored, per channel PAIR with v_dot2c on the packed values
+// (a pair never straddles a group: group sizes are even; both channels of a pair get (mean, M2 / 2), which merges to the
+// pair's exact moments downstream).
 template <bool F16>
 __device__ __forceinline__ unsigned pc_pack2(float a, float b) {
     return St<typename std::conditional<F16, f16_t, bf16_t>::type>::pack2(a, b);
 }
-
-constexpr int PCW_PITCH = 68;                              // floats per pixel row of the transposition tile (64 + 16 B)
-// RES: a residual is added (a uniform property of the launch; as a template parameter it costs no per-value selects).
-// Addressing: one per-lane byte offset per tile, every (t, i, k) increment is wave-uniform and travels in the buffer
-// instructions' scalar offset -- 64-bit per-pixel address arithmetic was ~250 of the stage's ~1 600 VALU instructions per
-// wave and tile, and VALU time adds to MFMA time on a SIMD.  Bias / residual / scale / statistics in packed fp32 pairs.
-// Where a tile's outputs (and residuals) live: per-sample buffer descriptors, one per-lane byte offset; every (t, i, k)
-// increment is wave-uniform (pc_osoff) and travels in the buffer instructions' scalar offset.
 struct PcOut {
-    __amdgpu_buffer_rsrc_t rs_out, rs_res;
-    unsigned voff;
-    int rowb, cstep;                                       // bytes per image row / per 8 pixels of a row
+    __amdgpu_buffer_rsrc_t rs_res;                         // the residual's sample
+    unsigned voff;                                         // this lane's byte offset: its pixel, its first channel
+    int rowb;                                              // bytes per image row
 };
-// NJ = 2: pixel (pl + 8 k) of row pair (t, i): row = y0 + 8 t + 2 (2 wm + i) + (k >> 1), column = x0 + pl + 8 (k & 1);
-// NJ = 1: pixel (pl + 16 k): row = ... + k, column = x0 + pl
-template <int NJ>
-__device__ __forceinline__ unsigned pc_osoff(const PcOut& o, int t, int i, int k) {
-    if (NJ == 2) return (unsigned)__builtin_amdgcn_readfirstlane((8 * t + 2 * i + (k >> 1)) * o.rowb + (k & 1) * o.cstep);
-    return (unsigned)__builtin_amdgcn_readfirstlane((8 * t + 2 * i + k) * o.rowb);
+// scalar byte offset of output round (t, i): image rows 8 t + 2 i (+ li >> 4) of the tile
+__device__ __forceinline__ unsigned pc_osoff(const PcOut& o, int t, int i) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((8 * t + 2 * i) * o.rowb);
 }
+typedef unsigned int pc_u32x2 __attribute__((ext_vector_type(2)));
 // Residuals and the next tile's B-fragment ring share the ring's 48 registers (explicitly: left to the allocator, early
-// residual requests were spilled to scratch behind an s_waitcnt vmcnt(0)).  Round r = 2 t + i of the stage:
+// residual requests were spilled to scratch behind an s_waitcnt vmcnt(0)).  A round (t, i) needs 4 NJ eight-byte pieces
+// (piece p = 4 j + q: channels 32 j + 8 q + 4 kh .. + 3 of the lane's pixel) = one ring entry.  Round r = 2 t + i:
 //   residual of round 0 / 1 / 2 arrives in wb[0] / wb[1] / wb[2], requested by the caller after the tile's last MFMAs on that
-//   entry (taps 6 / 7 / 8 of its last chunk: three to one steps before the stage -- a round-ahead request left ~1 000 cycles
-//   of latency per round exposed: 9.7 k vs 5.4 k cycles per tile with and without a residual, tools/pc16_ts.py); round 3's
-//   goes into wb[0] when round 0 has consumed it;
-// The next tile's first three ring entries are requested by the caller AFTER the stage (requested from inside it, into the
-// registers of consumed residuals, they were spilled as well): ~700 cycles of L2 latency per tile stay exposed.
-// NJ = 32-channel tiles per wave (2: 128-channel blocks; 1: 64-channel blocks for launches with too few items to fill the
-// chip, see launch_pc16): the transposition tile is [32 px][32 NJ ch], a lane reads 8 channels of the pixels pl + PL k.
-#define FLOWSE_PC_WBK(R, K) wb[R][NJ == 2 ? ((K) >> 1) : (K)][NJ == 2 ? ((K) & 1) : 0]   /* k-th 16-byte residual piece of a round */
+//   entry (taps 6 / 7 / 8 of its last chunk); round 3's goes into wb[0] when round 0 has consumed it.
+#define FLOWSE_PC_RQ(R, P) wb[R][NJ == 2 ? ((P) >> 2) : ((P) >> 1)][NJ == 2 ? (((P) >> 1) & 1) : 0]
+#define FLOWSE_PC_RSET(R, P, D)                                                                                      \
+    {                                                                                                                \
+        u32x4 rq_ = __builtin_bit_cast(u32x4, FLOWSE_PC_RQ(R, P));                                                   \
+        if ((P) & 1) { rq_.z = (D).x; rq_.w = (D).y; } else { rq_.x = (D).x; rq_.y = (D).y; }                        \
+        FLOWSE_PC_RQ(R, P) = __builtin_bit_cast(bf16x8, rq_);                                                        \
+    }
 template <class OT, bool RES, int NJ>
-__device__ __forceinline__ void pc16_out_wide(const ConvArgs& a, f32x16 (&acc)[2][2][NJ], float* T, float* red, int b, int y0,
-                                              int x0, int n0, int tiles_x, bf16x8 (&wb)[3][2][NJ], const PcOut& po) {
-    constexpr int OCT = 4 * NJ;                            // channel octets of the wave's tile
-    constexpr int PL = 64 / OCT;                           // pixel lanes
-    constexpr int KN = 32 / PL;                            // pixels per lane and (t, i) round
-    constexpr int NCH = 64 * NJ;                           // channels of the block
-    constexpr int TP = 32 * NJ + 4;                        // floats per pixel row of the transposition tile (+ 16 B)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kh = lane >> 5;
-    const int o = lane & (OCT - 1), pl = lane / OCT;       // read side: channel octet, pixel lane (pixels pl + PL k)
-    const int Cout = a.Cout;
-    const int ch0 = n0 + wn * (32 * NJ) + o * 8;           // this lane's 8 output channels
-    f32x2 bq[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) bq[e] = a.bias ? f32x2{a.bias[ch0 + 2 * e], a.bias[ch0 + 2 * e + 1]} : f32x2{0.f, 0.f};
-    if (a.bias2) {
-        const float* b2 = a.bias2 + (int64_t)b * a.bias2_stride + ch0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bq[e] += f32x2{b2[2 * e], b2[2 * e + 1]};
-    }
-    if (a.bias_x) {                                        // bias of the folded 1x1 shortcut
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bq[e] += f32x2{a.bias_x[ch0 + 2 * e], a.bias_x[ch0 + 2 * e + 1]};
-    }
+__device__ __forceinline__ void pc16_out_hand(const ConvArgs& a, f32x16 (&acc)[2][2][NJ], char* Ow, bf16x8 (&wb)[3][2][NJ],
+                                              const PcOut& po) {
+    constexpr int OP = pc_opitch(NJ);
     const f32x2 scale = {a.scale, a.scale};
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        f32x2 piv[4], s1[4], s2[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { piv[e] = f32x2{0.f, 0.f}; s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            // accumulators -> T[pixel][channel]: register r of tile j = pixel (r & 3) + 8 (r >> 2) + 4 kh, channel 32 j + li
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kh) * TP + j * 32 + li] = acc[t][i][j][r];
-#pragma unroll
-            for (int k = 0; k < KN; ++k) {
-                const float4 lo = *reinterpret_cast<const float4*>(T + (pl + PL * k) * TP + o * 8);
-                const float4 hi = *reinterpret_cast<const float4*>(T + (pl + PL * k) * TP + o * 8 + 4);
-                f32x2 v[4] = {f32x2{lo.x, lo.y}, f32x2{lo.z, lo.w}, f32x2{hi.x, hi.y}, f32x2{hi.z, hi.w}};
-                unsigned w[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x2 x = v[q] + bq[q];
-                    if (RES) {
-                        const u32x4 rr = __builtin_bit_cast(u32x4, FLOWSE_PC_WBK((2 * t + i) % 3, k));
-                        const unsigned rw = q == 0 ? rr.x : q == 1 ? rr.y : q == 2 ? rr.z : rr.w;
-                        float r0, r1;
-                        St<OT>::unpack2(rw, r0, r1);
-                        x += f32x2{r0, r1};
-                    }
-                    x *= scale;
-                    w[q] = St<OT>::pack2(x.x, x.y);
-                    float u0, u1;
-                    St<OT>::unpack2(w[q], u0, u1);                         // statistics of what is stored
-                    const f32x2 u = {u0, u1};
-                    if (i == 0 && k == 0) piv[q] = u;
-                    const f32x2 d = u - piv[q];
-                    s1[q] += d;
-                    s2[q] = __builtin_elementwise_fma(d, d, s2[q]);
+            for (int p = 0; p < 4 * NJ; ++p) {
+                const int j = p >> 2, q = p & 3;
+                f32x2 x0 = {acc[t][i][j][4 * q], acc[t][i][j][4 * q + 1]}, x1 = {acc[t][i][j][4 * q + 2], acc[t][i][j][4 * q + 3]};
+                if (RES) {
+                    const u32x4 rr = __builtin_bit_cast(u32x4, FLOWSE_PC_RQ((2 * t + i) % 3, p));
+                    float r0, r1, r2, r3;
+                    St<OT>::unpack2((p & 1) ? rr.z : rr.x, r0, r1);
+                    St<OT>::unpack2((p & 1) ? rr.w : rr.y, r2, r3);
+                    x0 += f32x2{r0, r1};
+                    x1 += f32x2{r2, r3};
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, po.rs_out, po.voff, pc_osoff<NJ>(po, t, i, k), FLOWSE_PC16_STORE_AUX);
-                if (RES && t == 0 && i == 0)                // round 3's residual into the registers round 0 just read
-                    FLOWSE_PC_WBK(0, k) = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                        po.rs_res, po.voff, pc_osoff<NJ>(po, 1, 1, k), 0));
+                x0 *= scale;
+                x1 *= scale;
+                const pc_u32x2 w = {St<OT>::pack2(x0.x, x0.y), St<OT>::pack2(x1.x, x1.y)};
+                *reinterpret_cast<pc_u32x2*>(Ow + ((8 * t + 2 * i) * 16) * OP + (32 * j + 8 * q) * 2) = w;
+            }
+            if (RES && t == 0 && i == 0) {                 // round 3's residual into the registers round 0 just read
+#pragma unroll
+                for (int p = 0; p < 4 * NJ; ++p) {
+                    const pc_u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(
+                        po.rs_res, po.voff + (unsigned)((32 * (p >> 2) + 8 * (p & 3)) * 2), pc_osoff(po, 1, 1), 0);
+                    FLOWSE_PC_RSET(0, p, d)
+                }
             }
         }
-        if (!a.stats) continue;
-        // 2 KN values per lane and channel -> the PL pixel lanes of the octet (64 = this wave's pixels of sub-tile t)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float pv = (e & 1) ? piv[e >> 1].y : piv[e >> 1].x;
-            const float a1 = (e & 1) ? s1[e >> 1].y : s1[e >> 1].x;
-            const float a2 = (e & 1) ? s2[e >> 1].y : s2[e >> 1].x;
-            constexpr float inv = 1.f / (2 * KN);
-            float mean = pv + a1 * inv;
-            float m2 = fmaxf(a2 - a1 * a1 * inv, 0.f);
-            float cnt = (float)(2 * KN);
-#pragma unroll
-            for (int off = OCT; off < 64; off <<= 1) {
-                const float mo = __shfl_xor(mean, off), qo = __shfl_xor(m2, off);
-                const float d = mo - mean;
-                m2 = m2 + qo + d * d * (0.5f * cnt);
-                mean = 0.5f * (mean + mo);
-                cnt *= 2.f;
-            }
-            if (pl == 0) {
-                float* dst = red + (((wm * 2 + t) * NCH) + wn * (32 * NJ) + o * 8 + e) * 2;
-                dst[0] = mean;
-                dst[1] = m2;
-            }
-        }
-    }
-    __syncthreads();                                       // (S) always: the producers match it
-    if (!a.stats) return;
-    if (tid < NCH) {
-        const int tile0 = (y0 >> 3) * tiles_x + (x0 >> 4);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float ma = red[((0 * 2 + t) * NCH + tid) * 2], qa = red[((0 * 2 + t) * NCH + tid) * 2 + 1];
-            const float mb = red[((1 * 2 + t) * NCH + tid) * 2], qb = red[((1 * 2 + t) * NCH + tid) * 2 + 1];
-            const float d = mb - ma;
-            float* dst = a.stats + (((int64_t)b * a.stats_nblk + tile0 + t * tiles_x) * Cout + n0 + tid) * 2;
-            dst[0] = 0.5f * (ma + mb);
-            dst[1] = qa + qb + d * d * 32.f;
-        }
-    }
 }
 
 template <int GN, bool F16, int NJ>
@@ -242,8 +161,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     PC_TS_ENTRY
     char* Hs = reinterpret_cast<char*>(smem);              // [PC_NHBUF][18][PC_HPITCH]
-    float* red = reinterpret_cast<float*>(Hs + PC_NHBUF * PC_HBUF_X);
-    float* tscr = red + PC_RED / 4;                        // [4 consumer waves][32][PCW_PITCH]
+    float* red = reinterpret_cast<float*>(Hs + PC_NHBUF * PC_HBUF_X);     // [2 strips][4 producer waves][NCH / 2][mean, M2]
+    char* Ob = Hs + PC_NHBUF * PC_HBUF_X + PC_RED;         // hand-off tile [256 pixels][pc_opitch(NJ)]
+    constexpr int OP = pc_opitch(NJ);
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -489,18 +409,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
                 w1 = w0 + jshort;
             }
         };
+        // The accumulators of an item START at bias + per-sample bias + shortcut bias of the lane's channels (transposed
+        // product: register r of tile j = channel 32 j + (r & 3) + 8 (r >> 2) + 4 kh of pixel li), so the output stage has no
+        // bias to add.  Branch-free: an absent table is a buffer of 0 records (loads return 0).
         f32x16 acc[2][2][NJ];
-        auto zero_acc = [&]() {
+        auto init_acc = [&](const PcItem& p) {
+            const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.bias2 ? a.bias2 + (int64_t)p.b * a.bias2_stride : a.bias2), 0, a.bias2 ? a.Cout * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rbx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias_x), 0, a.bias_x ? a.Cout * 4 : 0, 0x00020000);
+            const unsigned c0 = (unsigned)((p.n0 + wn * (32 * NJ) + 4 * kh) * 4);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned co = c0 + (unsigned)((32 * j + 8 * q) * 4);
+                    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rb1, co, 0, 0);
+                    const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rb2, co, 0, 0);
+                    const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(rbx, co, 0, 0);
+                    const float e[4] = {__uint_as_float(v1.x) + __uint_as_float(v2.x) + __uint_as_float(vx.x),
+                                        __uint_as_float(v1.y) + __uint_as_float(v2.y) + __uint_as_float(vx.y),
+                                        __uint_as_float(v1.z) + __uint_as_float(v2.z) + __uint_as_float(vx.z),
+                                        __uint_as_float(v1.w) + __uint_as_float(v2.w) + __uint_as_float(vx.w)};
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[t][i][j][4 * q + r] = e[r];
+                }
         };
-        zero_acc();
         // A step = two half-steps of 16 channels (mh = 0, 1), 8 MFMAs each.  The A fragments of half-step h + 1 are requested
         // before the MFMAs of half-step h (two sets of 4); the B fragments of a whole step travel through a ring of three
         // register sets, i.e. they are requested three steps (>= 1 500 cycles) before their MFMAs.
@@ -538,10 +476,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #define FLOWSE_PC_M1(FA, T_, I_, J_, R, MH)                                                                          \
     if (F16)                                                                                                         \
-        acc[T_][I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, FA[T_][I_]),              \
-                                                                __builtin_bit_cast(f16x8, wb[R][MH][J_]), acc[T_][I_][J_], 0, 0, 0); \
+        acc[T_][I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wb[R][MH][J_]),           \
+                                                                __builtin_bit_cast(f16x8, FA[T_][I_]), acc[T_][I_][J_], 0, 0, 0); \
     else                                                                                                             \
-        acc[T_][I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[T_][I_], wb[R][MH][J_], acc[T_][I_][J_], 0, 0, 0); \
+        acc[T_][I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[R][MH][J_], FA[T_][I_], acc[T_][I_][J_], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);
 #define FLOWSE_PC_REFILL(R, MH, J_, TAP)                                                                             \
     if constexpr ((TAP) + 3 < 9) { FLOWSE_PC_W1(R, MH, J_, wc0, wc1, (TAP) + 3) } else { FLOWSE_PC_W1(R, MH, J_, wn0, wn1, (TAP) + 3 - 9) }
@@ -615,11 +553,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         FLOWSE_PC_M1(ya, 1, 1, 0, R, 1) FLOWSE_PC_W1(R, 1, 0, wn0, wn1, 0)                                           \
         FLOWSE_PC_M1(ya, 1, 1, 1, R, 1) FLOWSE_PC_W1(R, 1, 1, wn0, wn1, 0)                                           \
     }
-#define FLOWSE_PC_RESLOAD(R)                               /* residual of output round R into ring entry R (see pc16_out_wide) */ \
+#define FLOWSE_PC_RESLOAD(R)                               /* residual of output round R into ring entry R (see pc16_out_hand) */ \
     if (tile_end && has_res) {                                                                                       \
-        _Pragma("unroll") for (int k = 0; k < 2 * NJ; ++k)                                                           \
-            FLOWSE_PC_WBK(R, k) = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                  \
-                po.rs_res, po.voff, pc_osoff<NJ>(po, (R) >> 1, (R) & 1, k), 0));                                     \
+        _Pragma("unroll") for (int p = 0; p < 4 * NJ; ++p) {                                                         \
+            const pc_u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(                                                 \
+                po.rs_res, po.voff + (unsigned)((32 * (p >> 2) + 8 * (p & 3)) * 2), pc_osoff(po, (R) >> 1, (R) & 1), 0); \
+            FLOWSE_PC_RSET(R, p, d)                                                                                  \
+        }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
         PC_TS_DECL
@@ -630,17 +570,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         PcItem pit = item_at(0);
         PcOut po;
         po.rowb = W * a.Cout * 2;
-        po.cstep = 16 * a.Cout;
-        auto set_out = [&]() {                             // descriptors and lane offset of tile `pit`
+        auto set_out = [&]() {                             // residual descriptor and lane offset of tile `pit`
             const int64_t sb = (int64_t)pit.b * H * W * a.Cout;
-            T16* ob = reinterpret_cast<T16*>(a.out) + sb;
-            const T16* rbase = has_res ? reinterpret_cast<const T16*>(a.res) + sb : ob;
-            po.rs_out = __builtin_amdgcn_make_buffer_rsrc(ob, 0, H * po.rowb, 0x00020000);
+            const T16* rbase = reinterpret_cast<const T16*>(has_res ? a.res : a.out) + sb;
             po.rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<T16*>(rbase), 0, H * po.rowb, 0x00020000);
-            po.voff = (unsigned)((((pit.y0 + 4 * wm) * W + pit.x0 + lane / (4 * NJ)) * a.Cout + pit.n0 + wn * (32 * NJ) +
-                                  (lane & (4 * NJ - 1)) * 8) * 2);
+            po.voff = (unsigned)((((pit.y0 + 4 * wm + (li >> 4)) * W + pit.x0 + (li & 15)) * a.Cout + pit.n0 + wn * (32 * NJ) +
+                                  4 * kh) * 2);
         };
         set_out();
+        init_acc(pit);
+        // this lane's corner of the hand-off tile: pixel (4 wm + (li >> 4), li & 15) of output round (0, 0), its first channel
+        char* const Ow = Ob + ((4 * wm + (li >> 4)) * 16 + (li & 15)) * OP + (wn * (32 * NJ) + 4 * kh) * 2;
+        const bool small_k = nct < 3;                      // fewer than three chunk intervals per tile: drained at the tile's end
         int hoff = 0;                                      // byte offset of the current chunk's halo buffer
         int nb_cur = (pit.n0 >> 5) + wn * NJ;              // this wave's first 32-channel block in the current / the next item
         auto nb_of = [&](int k) { return ((first + k * G8) % n_ntiles) * (2 * NJ) + wn * NJ; };
@@ -689,17 +630,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
                     }
                     gc += ns;
                 }
-                // the tile is complete: output stage (its block barrier (S) is matched by the producers), next tile
-                const PcItem p = pit;
-                if (has_res) pc16_out_wide<T16, true, NJ>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x, wb, po);
-                else pc16_out_wide<T16, false, NJ>(a, acc, tscr + wave * (32 * PCW_PITCH), red, p.b, p.y0, p.x0, p.n0, tiles_x, wb, po);
-                zero_acc();
+                // the tile is complete: rounded values into the hand-off tile (the producers drain it under the next tile's first
+                // chunks: the next chunk barrier publishes it, and they are done before this wave writes it again), next tile
+                if (has_res) pc16_out_hand<T16, true, NJ>(a, acc, Ow, wb, po);
+                else pc16_out_hand<T16, false, NJ>(a, acc, Ow, wb, po);
+                if (small_k) {                             // (launch-uniform) no interval to drain under: the producers drain here
+                    __syncthreads();
+                    __syncthreads();
+                }
                 cit = 0;
                 ++kitem;
                 pit = item_at(min(kitem, n_items - 1));
                 nb_cur = nb_next;
                 nb_next = nb_of(min(kitem + 1, n_items - 1));
                 set_out();
+                init_acc(pit);
                 PC_TS_ADD(3)                               // 3: output stage
                 if (has_res || ns) {                       // (else the ring still holds the refills of taps 6-8: the next tile's
                     chunk_off(nb_cur, 0, wc0, wc1);        //  steps 0-2)
@@ -709,6 +654,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
             }
         }
 #undef FLOWSE_PC_SCHUNK
+        if (!small_k) {                                    // the last tile: published by the first barrier, drained before the second
+            __syncthreads();
+            __syncthreads();
+        }
         PC_TS_EXIT
         if (wave == 0) { PC_TS_FLUSH(0) }                  // slots 0-7 of the block
 #undef FLOWSE_PC_RESLOAD
@@ -726,7 +675,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         return;
     }
 
-    // =================================================================================== producers: halo staging
+    // =================================================================================== producers: halo staging + drain
     // ---- prologue: chunk 0 -> buffer 0 (chunks 1 and 2: the consumer waves, above); raw pieces of chunks 3 and 4 in flight
     FLOWSE_PC_HLOAD(ra, hin_a, pa)
     rq_next();                                             // (chunks 1, 2)
@@ -736,37 +685,171 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     FLOWSE_PC_HLOAD(ra, hin_a, pa)
     PC_TS_DECL
     PC_TS_START
-    int cit = 0;
-    int hb = 3 * PC_HBUF_X;                                // buffer (byte offset) of chunk gc + 3
-    // One chunk interval gc + GO: after the chunk barrier the consumers work on chunk gc + GO and are done with chunk
-    // gc + GO - 1, whose buffer takes chunk gc + GO + 3 (raw pieces RX, requested two intervals ago); then the raw pieces
-    // of chunk gc + GO + 5 are requested into the same registers.  The staging runs two chunks ahead of what the next barrier
-    // needs.  (Four buffers instead of three changed nothing measurable: the consumers' ~1 250 cycles per chunk at the barrier
-    // are not a lack of slack -- per chunk the staging waves need as long as the MFMA waves, ~2 000 of their cycles in the
-    // request segment: twelve vector-memory instructions queued behind the consumers' 36 B-fragment loads per wave and
-    // chunk, ~170 KB per chunk through the CU's one vector-memory path.)
-#define FLOWSE_PC_LCHUNK(GO, RX, HINX, Q)                                                                            \
+    // ---- drain of the hand-off tile O (written by the consumers at the end of a tile, published by the next chunk barrier):
+    // a thread owns channel octet d_o of the pixels (row 8 T + RPP k + (d_pg >> 4), column d_pg & 15), k < NPH, of strip T
+    // (= the 8 x 16-pixel statistics block).  Strip 0 leaves in the next tile's first chunk interval, strip 1 in its second;
+    // each strip's partial statistics meet in `red` and are finished by NCH threads one interval later.
+    constexpr int OCT = 8 * NJ;                            // 16-byte pieces per pixel
+    constexpr int NPH = 4 * NJ;                            // pieces per thread and strip
+    constexpr int RPP = 2 / NJ;                            // image rows per pass of the 256 threads
+    const int d_o = ltid & (OCT - 1), d_pg = ltid / OCT;
+    const int d_lds = ((d_pg >> 4) * 16 + (d_pg & 15)) * OP + d_o * 16;
+    const int d_rowb = W * a.Cout * 2;
+    const int pwave = wave - 4;
+    PcItem dp = item_at(0);                                // the item being drained
+    __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T16*>(a.out), 0, 0, 0x00020000);
+    unsigned d_voff = 0;
+    auto drain_item = [&](int k) {
+        dp = item_at(k);
+        d_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T16*>(a.out) + (int64_t)dp.b * H * W * a.Cout, 0, H * d_rowb, 0x00020000);
+        d_voff = (unsigned)((((dp.y0 + (d_pg >> 4)) * W + dp.x0 + (d_pg & 15)) * a.Cout + dp.n0 + d_o * 8) * 2);
+    };
+    // One strip: NPH 16-byte pieces LDS -> global (write-through, see FLOWSE_PC16_STORE_AUX), and the moments of what is
+    // stored per channel PAIR: S1 = sum x, S2 = sum x^2 over the thread's 2 NPH values with ONE v_dot2c each per packed word
+    // (fp32 accumulation of exact products; half: about the thread's first value as pivot -- 22-bit squares do not sum exactly),
+    // equal-count Chan merges over the lanes that share the octet (64 values), then `red`.
+#define FLOWSE_PC_DRAIN(TS)                                                                                          \
+    {                                                                                                                \
+        u32x4 pc[NPH];                                                                                               \
+        _Pragma("unroll") for (int k = 0; k < NPH; ++k)                                                              \
+            pc[k] = *reinterpret_cast<const u32x4*>(Ob + d_lds + ((8 * (TS) + RPP * k) * 16) * OP);                  \
+        _Pragma("unroll") for (int k = 0; k < NPH; ++k)                                                              \
+            __builtin_amdgcn_raw_buffer_store_b128(pc[k], d_rs, d_voff,                                              \
+                (unsigned)__builtin_amdgcn_readfirstlane((8 * (TS) + RPP * k) * d_rowb), FLOWSE_PC16_STORE_AUX);     \
+        if (a.stats) {                                                                                               \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
+                const unsigned w0 = e == 0 ? pc[0].x : e == 1 ? pc[0].y : e == 2 ? pc[0].z : pc[0].w;               \
+                float s1 = 0.f, s2 = 0.f, pv = 0.f;                                                                  \
+                if (F16) {                                                                                           \
+                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));                                       \
+                    const unsigned pk = (w0 & 0xffffu) * 0x10001u;                                                   \
+                    pv = (float)__builtin_bit_cast(_Float16, (unsigned short)(w0 & 0xffffu));                        \
+                    _Pragma("unroll") for (int k = 0; k < NPH; ++k) {                                                \
+                        const unsigned wk = e == 0 ? pc[k].x : e == 1 ? pc[k].y : e == 2 ? pc[k].z : pc[k].w;       \
+                        const h2_t d = __builtin_bit_cast(h2_t, wk) - __builtin_bit_cast(h2_t, pk);                  \
+                        s1 = __builtin_amdgcn_fdot2(d, __builtin_bit_cast(h2_t, 0x3c003c00u), s1, false);            \
+                        s2 = __builtin_amdgcn_fdot2(d, d, s2, false);                                                \
+                    }                                                                                                \
+                } else {                                                                                             \
+                    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));                                         \
+                    _Pragma("unroll") for (int k = 0; k < NPH; ++k) {                                                \
+                        const unsigned wk = e == 0 ? pc[k].x : e == 1 ? pc[k].y : e == 2 ? pc[k].z : pc[k].w;       \
+                        s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, wk), __builtin_bit_cast(b2_t, 0x3f803f80u), s1, false); \
+                        s2 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, wk), __builtin_bit_cast(b2_t, wk), s2, false); \
+                    }                                                                                                \
+                }                                                                                                    \
+                constexpr float inv = 1.f / (2 * NPH);                                                               \
+                const float mr = s1 * inv;                 /* exact: a power of two */                               \
+                float m2 = fmaxf(__builtin_fmaf(-mr, s1, s2), 0.f);                                                  \
+                float mean = pv + mr;                                                                                \
+                float cnt = (float)(2 * NPH);                                                                        \
+                _Pragma("unroll") for (int off = OCT; off < 64; off <<= 1) {                                         \
+                    const float mo = __shfl_xor(mean, off), qo = __shfl_xor(m2, off);                                \
+                    const float dd = mo - mean;                                                                      \
+                    m2 = m2 + qo + dd * dd * (0.5f * cnt);                                                           \
+                    mean = 0.5f * (mean + mo);                                                                       \
+                    cnt *= 2.f;                                                                                      \
+                }                                                                                                    \
+                if ((tid & 63) < OCT) {                                                                              \
+                    float* dst = red + ((((TS) * 4 + pwave) * (NCH / 2)) + d_o * 4 + e) * 2;                         \
+                    dst[0] = mean;                                                                                   \
+                    dst[1] = m2;                                                                                     \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+    // the four producer waves' partials (64 values each) of strip TS -> the (mean, M2) of the strip's 128 pixels, per channel:
+    // both channels of a pair get (mean, M2 / 2) of the pair's 256 values
+#define FLOWSE_PC_FINAL(TS)                                                                                          \
+    if (a.stats && ltid < NCH) {                                                                                     \
+        const float* r0 = red + (((TS) * 4 + 0) * (NCH / 2) + (ltid >> 1)) * 2;                                      \
+        const float* r1 = r0 + (NCH / 2) * 2;                                                                        \
+        const float* r2 = r1 + (NCH / 2) * 2;                                                                        \
+        const float* r3 = r2 + (NCH / 2) * 2;                                                                        \
+        const float da = r1[0] - r0[0], db = r3[0] - r2[0];                                                          \
+        const float ma = 0.5f * (r0[0] + r1[0]), mb = 0.5f * (r2[0] + r3[0]);                                        \
+        const float qa = r0[1] + r1[1] + da * da * 32.f, qb = r2[1] + r3[1] + db * db * 32.f;                        \
+        const float dc = mb - ma;                                                                                    \
+        const int tile0 = (dp.y0 >> 3) * tiles_x + (dp.x0 >> 4);                                                     \
+        float* dst = a.stats + (((int64_t)dp.b * a.stats_nblk + tile0 + (TS) * tiles_x) * a.Cout + dp.n0 + ltid) * 2; \
+        dst[0] = 0.5f * (ma + mb);                                                                                   \
+        dst[1] = 0.5f * (qa + qb + dc * dc * 64.f);                                                                  \
+    }
+    const bool small_k = nct < 3;                          // fewer than three chunk intervals per tile: drained at the tile's end
+    int cit = 0;                                           // chunk (of the tile) of the current interval
+    int kt = 0;                                            // ordinal of the tile the consumers work on
+    int hb = 0;                                            // buffer (byte offset) of chunk g + 2
+    // One chunk interval g: after the chunk barrier the consumers work on chunk g and are done with chunk g - 1, whose buffer
+    // takes chunk g + 2 (raw pieces RX, requested two intervals ago); then the raw pieces of chunk g + 4 are requested into the
+    // same registers.  Three halo buffers (round 6: the fourth made room for the hand-off tile; rounds 4-5 measured three and
+    // four equal -- per chunk the staging waves need as long as the MFMA waves, ~2 000 of their cycles in the request segment:
+    // twelve vector-memory instructions queued behind the consumers' 36 B-fragment loads per wave and chunk).  The drain of
+    // the previous tile rides in front: stores first, so that they are older than this interval's requests.
+#define FLOWSE_PC_LCHUNK(STAGE, RX, HINX, Q)                                                                         \
     {                                                                                                                \
         const bool tile_end = cit == nct - 1;                                                                        \
-        __syncthreads();                                   /* (X gc + GO) */                                        \
+        __syncthreads();                                   /* (X g) */                                              \
         PC_TS_ADD(1)                                       /* 1: chunk barrier */                                   \
-        if (gc + (GO) + 3 < Ctot) { FLOWSE_PC_BURST(RX, HINX, Q, hb) }                                               \
-        hb = hb == (PC_NHBUF - 1) * PC_HBUF_X ? 0 : hb + PC_HBUF_X;                                                  \
-        PC_TS_ADD(4)                                       /* 4: halo burst */                                      \
-        FLOWSE_PC_HLOAD(RX, HINX, Q)                        /* chunk gc + GO + 5 */                                  \
-        PC_TS_ADD(0)                                       /* 0: requests */                                        \
+        if (!small_k && kt > 0) {                                                                                    \
+            if (cit == 0) {                                                                                          \
+                drain_item(kt - 1);                                                                                  \
+                FLOWSE_PC_DRAIN(0)                                                                                   \
+            } else if (cit == 1) {                                                                                   \
+                FLOWSE_PC_FINAL(0)                                                                                   \
+                FLOWSE_PC_DRAIN(1)                                                                                   \
+            } else if (cit == 2) {                                                                                   \
+                FLOWSE_PC_FINAL(1)                                                                                   \
+            }                                                                                                        \
+        }                                                                                                            \
+        PC_TS_ADD(3)                                       /* 3: drain */                                           \
+        if (STAGE) {                                                                                                 \
+            if (g + 2 < Ctot) { FLOWSE_PC_BURST(RX, HINX, Q, hb) }                                                   \
+            hb = hb == (PC_NHBUF - 1) * PC_HBUF_X ? 0 : hb + PC_HBUF_X;                                              \
+            PC_TS_ADD(4)                                   /* 4: halo burst */                                      \
+            FLOWSE_PC_HLOAD(RX, HINX, Q)                    /* chunk g + 4 */                                        \
+            PC_TS_ADD(0)                                   /* 0: requests */                                        \
+        }                                                                                                            \
         ++cit;                                                                                                       \
         if (tile_end) {                                                                                              \
             cit = 0;                                                                                                 \
-            __syncthreads();                               /* (S) the consumers' output-stage barrier */            \
-            PC_TS_ADD(3)                                   /* 3: waiting for the consumers' output stage */         \
+            if (small_k) {                                 /* (launch-uniform) the consumers' hand-off is complete after the first barrier */ \
+                __syncthreads();                                                                                     \
+                drain_item(kt);                                                                                      \
+                FLOWSE_PC_DRAIN(0)                                                                                   \
+                FLOWSE_PC_DRAIN(1)                                                                                   \
+                __syncthreads();                                                                                     \
+                FLOWSE_PC_FINAL(0)                                                                                   \
+                FLOWSE_PC_FINAL(1)                                                                                   \
+            }                                                                                                        \
+            ++kt;                                                                                                    \
         }                                                                                                            \
     }
-    for (int gc = 0; gc < Ctot; gc += 2) {
-        FLOWSE_PC_LCHUNK(0, rb, hin_b, pb)                 // rb holds chunk gc + 3
-        if (gc + 1 < Ctot) { FLOWSE_PC_LCHUNK(1, ra, hin_a, pa) }             // ra holds chunk gc + 4
+    {
+        const int g = 0;                                   // interval 0: all three buffers hold chunks 0-2, nothing to stage
+        FLOWSE_PC_LCHUNK(false, rb, hin_b, pb)
+    }
+    for (int g = 1; g < Ctot; g += 2) {
+        FLOWSE_PC_LCHUNK(true, rb, hin_b, pb)              // rb holds chunk g + 2
+        if (g + 1 < Ctot) {
+            const int g1 = g + 1;
+            {
+                const int g = g1;
+                FLOWSE_PC_LCHUNK(true, ra, hin_a, pa)      // ra holds chunk g + 2
+            }
+        }
+    }
+    if (!small_k) {                                        // the last tile
+        __syncthreads();
+        drain_item(n_items - 1);
+        FLOWSE_PC_DRAIN(0)
+        FLOWSE_PC_DRAIN(1)
+        __syncthreads();
+        FLOWSE_PC_FINAL(0)
+        FLOWSE_PC_FINAL(1)
     }
 #undef FLOWSE_PC_LCHUNK
+#undef FLOWSE_PC_FINAL
+#undef FLOWSE_PC_DRAIN
 #undef FLOWSE_PC_BURST
     PC_TS_EXIT
     if (wave == 4) { PC_TS_FLUSH(8) }                      // slots 8-15 of the block
@@ -866,11 +949,11 @@ int launch_pc16(const ConvArgs& a, hipStream_t s) {
 #define FLOWSE_LPC(GNF, F16)                                                                                 \
     {                                                                                                        \
         if (narrow) {                                                                                        \
-            if (const int rc = allow_lds<&conv3x3_pc16_kernel<GNF, F16, 1>>(PC_LDS)) return rc;              \
-            hipLaunchKernelGGL((conv3x3_pc16_kernel<GNF, F16, 1>), dim3(grid), dim3(512), PC_LDS, s, a);     \
+            if (const int rc = allow_lds<&conv3x3_pc16_kernel<GNF, F16, 1>>(pc_lds(1))) return rc;           \
+            hipLaunchKernelGGL((conv3x3_pc16_kernel<GNF, F16, 1>), dim3(grid), dim3(512), pc_lds(1), s, a);  \
         } else {                                                                                             \
-            if (const int rc = allow_lds<&conv3x3_pc16_kernel<GNF, F16, 2>>(PC_LDS)) return rc;              \
-            hipLaunchKernelGGL((conv3x3_pc16_kernel<GNF, F16, 2>), dim3(grid), dim3(512), PC_LDS, s, a);     \
+            if (const int rc = allow_lds<&conv3x3_pc16_kernel<GNF, F16, 2>>(pc_lds(2))) return rc;           \
+            hipLaunchKernelGGL((conv3x3_pc16_kernel<GNF, F16, 2>), dim3(grid), dim3(512), pc_lds(2), s, a);  \
         }                                                                                                    \
     }
     if (a.wq_f16) {

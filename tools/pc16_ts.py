@@ -58,9 +58,9 @@ def main():
     buf = (C.c_ulonglong * (256 * 16))()
     raw.flowse_debug_pc_ts(buf, 256 * 16)
     t = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16).astype(np.float64)
-    names = ["cons: frag+mfma", "cons: chunk barrier", "", "cons: output stage", "", "cons: kernel entry -> loop end (ticks)",
+    names = ["cons: frag+mfma", "cons: chunk barrier", "", "cons: hand-off (round 6) + next tile setup", "", "cons: kernel entry -> loop end (ticks)",
              "cons: the same on the 100 MHz counter", "",
-             "prod: requests", "prod: chunk barrier", "", "prod: output-stage wait", "prod: halo bursts",
+             "prod: requests", "prod: chunk barrier", "", "prod: drain of the hand-off tile", "prod: halo bursts",
              "prod: kernel entry -> loop end (ticks)", "prod: the same on the 100 MHz counter"]
     live = t[:, 5] > 0                                       # blocks that ran (a launch may have fewer than 256)
     for k, n in enumerate(names):
