@@ -100,58 +100,52 @@ struct PcOut {
     unsigned voff;                                         // this lane's byte offset: its pixel, its first channel
     int rowb;                                              // bytes per image row
 };
-// scalar byte offset of output round (t, i): image rows 8 t + 2 i (+ li >> 4) of the tile
-__device__ __forceinline__ unsigned pc_osoff(const PcOut& o, int t, int i) {
-    return (unsigned)__builtin_amdgcn_readfirstlane((8 * t + 2 * i) * o.rowb);
+// scalar byte offset of output round pt (= the wave's pixel tile pt): two image rows per tile
+__device__ __forceinline__ unsigned pc_osoff(const PcOut& o, int pt) {
+    return (unsigned)__builtin_amdgcn_readfirstlane(2 * pt * o.rowb);
 }
 typedef unsigned int pc_u32x2 __attribute__((ext_vector_type(2)));
-// Residuals and the next tile's B-fragment ring share the ring's 48 registers (explicitly: left to the allocator, early
-// residual requests were spilled to scratch behind an s_waitcnt vmcnt(0)).  A round (t, i) needs 4 NJ eight-byte pieces
-// (piece p = 4 j + q: channels 32 j + 8 q + 4 kh .. + 3 of the lane's pixel) = one ring entry.  Round r = 2 t + i:
-//   residual of round 0 / 1 / 2 arrives in wb[0] / wb[1] / wb[2], requested by the caller after the tile's last MFMAs on that
-//   entry (taps 6 / 7 / 8 of its last chunk); round 3's goes into wb[0] when round 0 has consumed it.
-#define FLOWSE_PC_RQ(R, P) wb[R][NJ == 2 ? ((P) >> 2) : ((P) >> 1)][NJ == 2 ? (((P) >> 1) & 1) : 0]
-#define FLOWSE_PC_RSET(R, P, D)                                                                                      \
+// Residuals and the next tile's B-fragment ring share the ring's 24 registers (explicitly: left to the allocator, early
+// residual requests were spilled to scratch behind an s_waitcnt vmcnt(0)).  A round (= pixel tile) needs four eight-byte
+// pieces (piece q: channels 8 q + 4 kh .. + 3 of the lane's pixel) = one ring entry.  The residuals of rounds 0 / 1 / 2
+// arrive in wb[0] / wb[1] / wb[2], requested by the caller after the tile's last MFMAs on that entry (taps 6 / 7 / 8 of its
+// last chunk); round r + 3's goes into wb[r % 3] when round r has consumed it.
+#define FLOWSE_PC_RSET(R, Q, D)                                                                                      \
     {                                                                                                                \
-        u32x4 rq_ = __builtin_bit_cast(u32x4, FLOWSE_PC_RQ(R, P));                                                   \
-        if ((P) & 1) { rq_.z = (D).x; rq_.w = (D).y; } else { rq_.x = (D).x; rq_.y = (D).y; }                        \
-        FLOWSE_PC_RQ(R, P) = __builtin_bit_cast(bf16x8, rq_);                                                        \
+        u32x4 rq_ = __builtin_bit_cast(u32x4, wb[R][(Q) >> 1]);                                                      \
+        if ((Q) & 1) { rq_.z = (D).x; rq_.w = (D).y; } else { rq_.x = (D).x; rq_.y = (D).y; }                        \
+        wb[R][(Q) >> 1] = __builtin_bit_cast(bf16x8, rq_);                                                           \
     }
-template <class OT, bool RES, int NJ>
-__device__ __forceinline__ void pc16_out_hand(const ConvArgs& a, f32x16 (&acc)[2][2][NJ], char* Ow, bf16x8 (&wb)[3][2][NJ],
-                                              const PcOut& po) {
-    constexpr int OP = pc_opitch(NJ);
+template <class OT, bool RES, int PT>
+__device__ __forceinline__ void pc16_out_hand(const ConvArgs& a, f32x16 (&acc)[PT], char* Ow, bf16x8 (&wb)[3][2], const PcOut& po) {
+    constexpr int OP = pc_opitch(PT / 4);
     const f32x2 scale = {a.scale, a.scale};
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int pt = 0; pt < PT; ++pt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int p = 0; p < 4 * NJ; ++p) {
-                const int j = p >> 2, q = p & 3;
-                f32x2 x0 = {acc[t][i][j][4 * q], acc[t][i][j][4 * q + 1]}, x1 = {acc[t][i][j][4 * q + 2], acc[t][i][j][4 * q + 3]};
-                if (RES) {
-                    const u32x4 rr = __builtin_bit_cast(u32x4, FLOWSE_PC_RQ((2 * t + i) % 3, p));
-                    float r0, r1, r2, r3;
-                    St<OT>::unpack2((p & 1) ? rr.z : rr.x, r0, r1);
-                    St<OT>::unpack2((p & 1) ? rr.w : rr.y, r2, r3);
-                    x0 += f32x2{r0, r1};
-                    x1 += f32x2{r2, r3};
-                }
-                x0 *= scale;
-                x1 *= scale;
-                const pc_u32x2 w = {St<OT>::pack2(x0.x, x0.y), St<OT>::pack2(x1.x, x1.y)};
-                *reinterpret_cast<pc_u32x2*>(Ow + ((8 * t + 2 * i) * 16) * OP + (32 * j + 8 * q) * 2) = w;
+        for (int q = 0; q < 4; ++q) {
+            f32x2 x0 = {acc[pt][4 * q], acc[pt][4 * q + 1]}, x1 = {acc[pt][4 * q + 2], acc[pt][4 * q + 3]};
+            if (RES) {
+                const u32x4 rr = __builtin_bit_cast(u32x4, wb[pt % 3][q >> 1]);
+                float r0, r1, r2, r3;
+                St<OT>::unpack2((q & 1) ? rr.z : rr.x, r0, r1);
+                St<OT>::unpack2((q & 1) ? rr.w : rr.y, r2, r3);
+                x0 += f32x2{r0, r1};
+                x1 += f32x2{r2, r3};
             }
-            if (RES && t == 0 && i == 0) {                 // round 3's residual into the registers round 0 just read
+            x0 *= scale;
+            x1 *= scale;
+            const pc_u32x2 w = {St<OT>::pack2(x0.x, x0.y), St<OT>::pack2(x1.x, x1.y)};
+            *reinterpret_cast<pc_u32x2*>(Ow + (2 * pt * 16) * OP + 8 * q * 2) = w;
+        }
+        if (RES && pt + 3 < PT) {                          // round pt + 3's residual into the registers this round just read
 #pragma unroll
-                for (int p = 0; p < 4 * NJ; ++p) {
-                    const pc_u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(
-                        po.rs_res, po.voff + (unsigned)((32 * (p >> 2) + 8 * (p & 3)) * 2), pc_osoff(po, 1, 1), 0);
-                    FLOWSE_PC_RSET(0, p, d)
-                }
+            for (int q = 0; q < 4; ++q) {
+                const pc_u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(po.rs_res, po.voff + (unsigned)(q * 16), pc_osoff(po, pt + 3), 0);
+                FLOWSE_PC_RSET(pt % 3, q, d)
             }
         }
+    }
 }
 
 template <int GN, bool F16, int NJ>
@@ -377,16 +371,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         FLOWSE_PC_HLOAD(rb, hin_b, pb)
         FLOWSE_PC_BURST(ra, hin_a, pa, PC_HBUF_X)
         FLOWSE_PC_BURST(rb, hin_b, pb, 2 * PC_HBUF_X)
+        // Wave tiling (round 6): a consumer wave owns ONE 32-channel tile of the block and PT 32-pixel tiles (two image rows
+        // each) -- with 128-channel blocks all 256 pixels x channels 32 wave .. + 31, so that every B-fragment line crosses the
+        // CU's vector-memory path ONCE (rounds 4-5: 2 x 2 waves of 128 pixels x 64 channels fetched each line twice, ~145 KB of
+        // B fragments per chunk and CU = two thirds of that path's time; now 72 KB, paid for with twice the ds_read_b128 of A
+        // fragments: 64 KB per step and CU = half of the LDS read rate); 64-channel blocks: 2 pixel halves x 2 channel tiles.
+        constexpr int PT = 4 * NJ;
         const int lane = tid & 63;
-        const int wm = wave >> 1, wn = wave & 1;
+        const int wn = NJ == 2 ? wave : (wave & 1);        // the wave's 32-channel tile of the block
+        const int r0 = NJ == 2 ? 0 : 8 * (wave >> 1);      // its first image row of the tile
         const int li = lane & 31, kh = lane >> 5;
-        int abase[2];                                      // sub-tile 0; sub-tile t adds 8 image rows
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int py = 2 * (wm * 2 + i) + (li >> 4), px = li & 15;
-            abase[i] = (py + 1) * PC_HPITCH + (px + 1) * PC_ROWB + kh * 16;
-        }
-        // weights in fragment order (pc16_weights_kernel): one buffer_load_b128 per wave = one MFMA B operand, 1 KB contiguous.
+        // pixel tile 0 of the wave: rows r0 + (li >> 4), column li & 15; pixel tile pt adds two image rows
+        const int abase = (r0 + (li >> 4) + 1) * PC_HPITCH + ((li & 15) + 1) * PC_ROWB + kh * 16;
+        // weights in fragment order (pc16_weights_kernel): one buffer_load_b128 per wave = one MFMA operand, 1 KB contiguous.
         // ONE descriptor spans the 3x3 fragments and (folded shortcut) the 1x1 fragments: byte offsets o1 / o2 from the lower one
         const char* wf1 = static_cast<const char*>(a.wfrag);
         const char* wf2 = ns ? static_cast<const char*>(a.wfrag_sc) : wf1;
@@ -396,169 +393,107 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         const __amdgpu_buffer_rsrc_t rsrcw =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wlow), 0, (int)(e1 > e2 ? e1 : e2), 0x00020000);
         const unsigned bvo = (unsigned)lane * 16u;
-        const unsigned jstride = (unsigned)nchunks * PCF_CHUNK;   // bytes between two 32-channel blocks: nine-tap chunks ...
-        const unsigned jshort = (unsigned)ns * PCF_STEP;          // ... and the shortcut's one-step chunks
-        // byte offsets of chunk c of 32-channel block nb (w0) and of block nb + 1 (w1): no division, a handful of scalar
-        // instructions per chunk
-        auto chunk_off = [&](int nb, int c, unsigned& w0, unsigned& w1) {
-            if (c < nchunks) {
-                w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(o1 + (unsigned)(nb * nchunks + c) * PCF_CHUNK));
-                w1 = w0 + jstride;
-            } else {
-                w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(o2 + (unsigned)(nb * ns + (c - nchunks)) * PCF_STEP));
-                w1 = w0 + jshort;
-            }
+        // byte offset of chunk c of 32-channel block nb: no division, a handful of scalar instructions per chunk
+        auto chunk_off = [&](int nb, int c, unsigned& w0) {
+            if (c < nchunks) w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(o1 + (unsigned)(nb * nchunks + c) * PCF_CHUNK));
+            else w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(o2 + (unsigned)(nb * ns + (c - nchunks)) * PCF_STEP));
         };
         // The accumulators of an item START at bias + per-sample bias + shortcut bias of the lane's channels (transposed
-        // product: register r of tile j = channel 32 j + (r & 3) + 8 (r >> 2) + 4 kh of pixel li), so the output stage has no
-        // bias to add.  Branch-free: an absent table is a buffer of 0 records (loads return 0).
-        f32x16 acc[2][2][NJ];
+        // product: register r of a tile = channel (r & 3) + 8 (r >> 2) + 4 kh of pixel li), so the output stage has no bias to
+        // add.  Branch-free: an absent table is a buffer of 0 records (loads return 0).
+        f32x16 acc[PT];
         auto init_acc = [&](const PcItem& p) {
             const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a.bias2 ? a.bias2 + (int64_t)p.b * a.bias2_stride : a.bias2), 0, a.bias2 ? a.Cout * 4 : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rbx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias_x), 0, a.bias_x ? a.Cout * 4 : 0, 0x00020000);
-            const unsigned c0 = (unsigned)((p.n0 + wn * (32 * NJ) + 4 * kh) * 4);
+            const unsigned c0 = (unsigned)((p.n0 + wn * 32 + 4 * kh) * 4);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+            for (int q = 0; q < 4; ++q) {
+                const unsigned co = c0 + (unsigned)(8 * q * 4);
+                const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rb1, co, 0, 0);
+                const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rb2, co, 0, 0);
+                const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(rbx, co, 0, 0);
+                const float e[4] = {__uint_as_float(v1.x) + __uint_as_float(v2.x) + __uint_as_float(vx.x),
+                                    __uint_as_float(v1.y) + __uint_as_float(v2.y) + __uint_as_float(vx.y),
+                                    __uint_as_float(v1.z) + __uint_as_float(v2.z) + __uint_as_float(vx.z),
+                                    __uint_as_float(v1.w) + __uint_as_float(v2.w) + __uint_as_float(vx.w)};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned co = c0 + (unsigned)((32 * j + 8 * q) * 4);
-                    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rb1, co, 0, 0);
-                    const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rb2, co, 0, 0);
-                    const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(rbx, co, 0, 0);
-                    const float e[4] = {__uint_as_float(v1.x) + __uint_as_float(v2.x) + __uint_as_float(vx.x),
-                                        __uint_as_float(v1.y) + __uint_as_float(v2.y) + __uint_as_float(vx.y),
-                                        __uint_as_float(v1.z) + __uint_as_float(v2.z) + __uint_as_float(vx.z),
-                                        __uint_as_float(v1.w) + __uint_as_float(v2.w) + __uint_as_float(vx.w)};
+                for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[t][i][j][4 * q + r] = e[r];
-                }
+                    for (int r = 0; r < 4; ++r) acc[pt][4 * q + r] = e[r];
+            }
         };
-        // A step = two half-steps of 16 channels (mh = 0, 1), 8 MFMAs each.  The A fragments of half-step h + 1 are requested
-        // before the MFMAs of half-step h (two sets of 4); the B fragments of a whole step travel through a ring of three
-        // register sets, i.e. they are requested three steps (>= 1 500 cycles) before their MFMAs.
-        bf16x8 xa[2][2], ya[2][2];                         // [t][i]
-        bf16x8 wb[3][2][NJ];                               // [ring][mh][j]
+        // A step = two half-steps of 16 channels (mh = 0, 1), PT MFMAs each, every one with its own A fragment: a ring of PT
+        // fragment registers, each refilled right behind the MFMA that read it with the fragment of the MFMA PT ahead (the same
+        // pixel tile's next half-step).  The B fragments of a whole step travel through a ring of three register sets, i.e. they
+        // are requested three steps (>= 1 500 cycles) before their MFMAs.
+        bf16x8 fa[PT];                                     // [pixel tile]
+        bf16x8 wb[3][2];                                   // [ring][mh]
 
-#define FLOWSE_PC_LOADA(FA, HOFF, TAP, MH)                                                                           \
-    {                                                                                                                \
-        constexpr int tapoff = ((TAP) / 3 - 1) * PC_HPITCH + ((TAP) % 3 - 1) * PC_ROWB + (MH) * 32;                  \
-        const char* Hb = Hs + (HOFF) + tapoff;                                                                       \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i)                  \
-            FA[t][i] = *reinterpret_cast<const bf16x8*>(Hb + abase[i] + t * 8 * PC_HPITCH);                          \
-    }
-#define FLOWSE_PC_WLOAD(RING, S0, S1, TAPV)                                                                          \
-    _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                  \
-        wb[RING][mh][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                          \
-            rsrcw, bvo, (j ? (S1) : (S0)) + (unsigned)((TAPV) * PCF_STEP + mh * 1024), 0));
-        // One step at tap TAP of the current chunk (halo buffer offset hoff, B ring entry R = TAP % 3): 16 MFMAs with every other
-        // instruction of the step placed in the gap behind ONE of them -- a lone MFMA wave hides at most ~5 issue slots per
-        // 32-cycle MFMA (MI355X_MICROARCH.md), and in clumps (four ds_read + four buffer_load + their scalar adds behind one
-        // MFMA, as the compiler's own order had it) the loop ran at 41 cycles per MFMA (tools/pc16_ts.py).  Gap after MFMA
-        //   1-4   this tap's second-half A fragments (set Y),        7, 8   refill of ring entry R, first half (step + 3),
-        //   9-12  the next step's first-half A fragments (set X),    15, 16 refill of ring entry R, second half.
+#define FLOWSE_PC_LOADA(HOFF)                                                                                        \
+    _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)                                                                \
+        fa[pt] = *reinterpret_cast<const bf16x8*>(Hs + (HOFF) + (-PC_HPITCH - PC_ROWB) + pt * 2 * PC_HPITCH + abase);
+#define FLOWSE_PC_WLOAD(RING, S0, TAPV)                                                                              \
+    _Pragma("unroll") for (int mh = 0; mh < 2; ++mh)                                                                 \
+        wb[RING][mh] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                             \
+            rsrcw, bvo, (S0) + (unsigned)((TAPV) * PCF_STEP + mh * 1024), 0));
+        // One step at tap TAP of the current chunk (halo buffer offset hoff, B ring entry R = TAP % 3): 2 PT MFMAs with every
+        // other instruction of the step placed in the gap behind ONE of them -- a lone MFMA wave hides at most ~5 issue slots
+        // per 32-cycle MFMA (MI355X_MICROARCH.md), and in clumps (four ds_read + four buffer_load + their scalar adds behind one
+        // MFMA, as the compiler's own order had it) the loop ran at 41 cycles per MFMA (tools/pc16_ts.py).  Behind MFMA
+        // (mh, pt): the A fragment of (mh + 1, pt) -- this tap's second half, or the next step's first; behind the last MFMA
+        // of a half-step also the refill of ring entry R, that half (step + 3).
         // Branch-free: across a chunk boundary the next halo is complete since the barrier of THIS chunk; in a tile's last
         // chunk the requests for "the next chunk" are redundant (the ring is re-requested after the output stage, entries 0-2
         // meanwhile take the residuals: FLOWSE_PC_RESLOAD).
-#define FLOWSE_PC_A1(FA, T_, I_, HOFF, TAP, MH)                                                                      \
-    FA[T_][I_] = *reinterpret_cast<const bf16x8*>(Hs + (HOFF) + (((TAP) / 3 - 1) * PC_HPITCH + ((TAP) % 3 - 1) * PC_ROWB + \
-                                                                (MH) * 32 + (T_) * 8 * PC_HPITCH) + abase[I_]);      \
+#define FLOWSE_PC_A1(PT_, HOFF, TAP, MH)                                                                             \
+    fa[PT_] = *reinterpret_cast<const bf16x8*>(Hs + (HOFF) + (((TAP) / 3 - 1) * PC_HPITCH + ((TAP) % 3 - 1) * PC_ROWB + \
+                                                             (MH) * 32 + (PT_) * 2 * PC_HPITCH) + abase);            \
     __builtin_amdgcn_sched_barrier(0);
-#define FLOWSE_PC_W1(R, MH, J_, S0, S1, TAPV)                                                                        \
-    wb[R][MH][J_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                                \
-        rsrcw, bvo + (unsigned)(((TAPV) & 1) * PCF_STEP + (MH) * 1024),                                              \
-        ((J_) ? (S1) : (S0)) + (unsigned)(((TAPV) >> 1) * 2 * PCF_STEP), 0));                                        \
+#define FLOWSE_PC_W1(R, MH, S0, TAPV)                                                                                \
+    wb[R][MH] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                                    \
+        rsrcw, bvo + (unsigned)(((TAPV) & 1) * PCF_STEP + (MH) * 1024), (S0) + (unsigned)(((TAPV) >> 1) * 2 * PCF_STEP), 0)); \
     __builtin_amdgcn_sched_barrier(0);
-#define FLOWSE_PC_M1(FA, T_, I_, J_, R, MH)                                                                          \
+#define FLOWSE_PC_M1(PT_, R, MH)                                                                                     \
     if (F16)                                                                                                         \
-        acc[T_][I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wb[R][MH][J_]),           \
-                                                                __builtin_bit_cast(f16x8, FA[T_][I_]), acc[T_][I_][J_], 0, 0, 0); \
+        acc[PT_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wb[R][MH]),                      \
+                                                         __builtin_bit_cast(f16x8, fa[PT_]), acc[PT_], 0, 0, 0);    \
     else                                                                                                             \
-        acc[T_][I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[R][MH][J_], FA[T_][I_], acc[T_][I_][J_], 0, 0, 0); \
+        acc[PT_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[R][MH], fa[PT_], acc[PT_], 0, 0, 0);                   \
     __builtin_amdgcn_sched_barrier(0);
-#define FLOWSE_PC_REFILL(R, MH, J_, TAP)                                                                             \
-    if constexpr ((TAP) + 3 < 9) { FLOWSE_PC_W1(R, MH, J_, wc0, wc1, (TAP) + 3) } else { FLOWSE_PC_W1(R, MH, J_, wn0, wn1, (TAP) + 3 - 9) }
-#define FLOWSE_PC_NEXTA(T_, I_, TAP)                                                                                 \
-    if constexpr ((TAP) < 8) { FLOWSE_PC_A1(xa, T_, I_, hoff, (TAP) + 1, 0) } else { FLOWSE_PC_A1(xa, T_, I_, hnext, 0, 0) }
-        // NJ = 1 (64-channel blocks): eight MFMAs per step, every A fragment requested four MFMAs ahead of its use
-#define FLOWSE_PC_STEP_N1(TAP)                                                                                       \
-    {                                                                                                                \
-        constexpr int R = (TAP) % 3;                                                                                 \
-        FLOWSE_PC_M1(xa, 0, 0, 0, R, 0) FLOWSE_PC_A1(ya, 0, 0, hoff, (TAP), 1)                                       \
-        FLOWSE_PC_M1(xa, 0, 1, 0, R, 0) FLOWSE_PC_A1(ya, 0, 1, hoff, (TAP), 1)                                       \
-        FLOWSE_PC_M1(xa, 1, 0, 0, R, 0) FLOWSE_PC_A1(ya, 1, 0, hoff, (TAP), 1)                                       \
-        FLOWSE_PC_M1(xa, 1, 1, 0, R, 0) FLOWSE_PC_A1(ya, 1, 1, hoff, (TAP), 1) FLOWSE_PC_REFILL(R, 0, 0, TAP)        \
-        FLOWSE_PC_M1(ya, 0, 0, 0, R, 1) FLOWSE_PC_NEXTA(0, 0, TAP)                                                   \
-        FLOWSE_PC_M1(ya, 0, 1, 0, R, 1) FLOWSE_PC_NEXTA(0, 1, TAP)                                                   \
-        FLOWSE_PC_M1(ya, 1, 0, 0, R, 1) FLOWSE_PC_NEXTA(1, 0, TAP)                                                   \
-        FLOWSE_PC_M1(ya, 1, 1, 0, R, 1) FLOWSE_PC_NEXTA(1, 1, TAP) FLOWSE_PC_REFILL(R, 1, 0, TAP)                    \
-    }
-#define FLOWSE_PC_SSTEP_N1(R)                                                                                        \
-    {                                                                                                                \
-        FLOWSE_PC_M1(xa, 0, 0, 0, R, 0) FLOWSE_PC_A1(ya, 0, 0, hoff, 0, 1)                                           \
-        FLOWSE_PC_M1(xa, 0, 1, 0, R, 0) FLOWSE_PC_A1(ya, 0, 1, hoff, 0, 1)                                           \
-        FLOWSE_PC_M1(xa, 1, 0, 0, R, 0) FLOWSE_PC_A1(ya, 1, 0, hoff, 0, 1)                                           \
-        FLOWSE_PC_M1(xa, 1, 1, 0, R, 0) FLOWSE_PC_A1(ya, 1, 1, hoff, 0, 1) FLOWSE_PC_W1(R, 0, 0, wn0, wn1, 0)        \
-        FLOWSE_PC_M1(ya, 0, 0, 0, R, 1) FLOWSE_PC_A1(xa, 0, 0, hnext, 0, 0)                                          \
-        FLOWSE_PC_M1(ya, 0, 1, 0, R, 1) FLOWSE_PC_A1(xa, 0, 1, hnext, 0, 0)                                          \
-        FLOWSE_PC_M1(ya, 1, 0, 0, R, 1) FLOWSE_PC_A1(xa, 1, 0, hnext, 0, 0)                                          \
-        FLOWSE_PC_M1(ya, 1, 1, 0, R, 1) FLOWSE_PC_A1(xa, 1, 1, hnext, 0, 0) FLOWSE_PC_W1(R, 1, 0, wn0, wn1, 0)       \
-    }
 #define FLOWSE_PC_STEP(TAP)                                                                                          \
-    if constexpr (NJ == 1) FLOWSE_PC_STEP_N1(TAP) else                                                               \
     {                                                                                                                \
         constexpr int R = (TAP) % 3;                                                                                 \
-        FLOWSE_PC_M1(xa, 0, 0, 0, R, 0) FLOWSE_PC_A1(ya, 0, 0, hoff, (TAP), 1)                                       \
-        FLOWSE_PC_M1(xa, 0, 0, 1, R, 0) FLOWSE_PC_A1(ya, 0, 1, hoff, (TAP), 1)                                       \
-        FLOWSE_PC_M1(xa, 0, 1, 0, R, 0) FLOWSE_PC_A1(ya, 1, 0, hoff, (TAP), 1)                                       \
-        FLOWSE_PC_M1(xa, 0, 1, 1, R, 0) FLOWSE_PC_A1(ya, 1, 1, hoff, (TAP), 1)                                       \
-        FLOWSE_PC_M1(xa, 1, 0, 0, R, 0)                                                                              \
-        FLOWSE_PC_M1(xa, 1, 0, 1, R, 0)                                                                              \
-        FLOWSE_PC_M1(xa, 1, 1, 0, R, 0) FLOWSE_PC_REFILL(R, 0, 0, TAP)                                               \
-        FLOWSE_PC_M1(xa, 1, 1, 1, R, 0) FLOWSE_PC_REFILL(R, 0, 1, TAP)                                               \
-        FLOWSE_PC_M1(ya, 0, 0, 0, R, 1) FLOWSE_PC_NEXTA(0, 0, TAP)                                                   \
-        FLOWSE_PC_M1(ya, 0, 0, 1, R, 1) FLOWSE_PC_NEXTA(0, 1, TAP)                                                   \
-        FLOWSE_PC_M1(ya, 0, 1, 0, R, 1) FLOWSE_PC_NEXTA(1, 0, TAP)                                                   \
-        FLOWSE_PC_M1(ya, 0, 1, 1, R, 1) FLOWSE_PC_NEXTA(1, 1, TAP)                                                   \
-        FLOWSE_PC_M1(ya, 1, 0, 0, R, 1)                                                                              \
-        FLOWSE_PC_M1(ya, 1, 0, 1, R, 1)                                                                              \
-        FLOWSE_PC_M1(ya, 1, 1, 0, R, 1) FLOWSE_PC_REFILL(R, 1, 0, TAP)                                               \
-        FLOWSE_PC_M1(ya, 1, 1, 1, R, 1) FLOWSE_PC_REFILL(R, 1, 1, TAP)                                               \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) {                                                          \
+            FLOWSE_PC_M1(pt, R, 0) FLOWSE_PC_A1(pt, hoff, (TAP), 1)                                                  \
+        }                                                                                                            \
+        if constexpr ((TAP) + 3 < 9) { FLOWSE_PC_W1(R, 0, wc0, (TAP) + 3) } else { FLOWSE_PC_W1(R, 0, wn0, (TAP) + 3 - 9) } \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) {                                                          \
+            FLOWSE_PC_M1(pt, R, 1)                                                                                   \
+            if constexpr ((TAP) < 8) { FLOWSE_PC_A1(pt, hoff, (TAP) + 1, 0) } else { FLOWSE_PC_A1(pt, hnext, 0, 0) } \
+        }                                                                                                            \
+        if constexpr ((TAP) + 3 < 9) { FLOWSE_PC_W1(R, 1, wc0, (TAP) + 3) } else { FLOWSE_PC_W1(R, 1, wn0, (TAP) + 3 - 9) } \
     }
-        // One step of a folded-shortcut chunk (ring entry R = its ordinal % 3): the STEP schedule with tap-0 addressing -- the
-        // chunk's pixels are staged unshifted --, the refill of entry R comes from the shortcut step three ahead (wn0 / wn1, the
-        // last one again past the end) and the next A fragments from the next chunk's buffer.
+        // One step of a folded-shortcut chunk (ring entry R = its ordinal % 3): the STEP schedule with tap-4 (centre) data staged
+        // unshifted, i.e. tap-0 addressing; the refill of entry R comes from the shortcut step three ahead (wn0, the last one
+        // again past the end) and the next A fragments from the next chunk's buffer.
 #define FLOWSE_PC_SSTEP(R)                                                                                           \
-    if constexpr (NJ == 1) FLOWSE_PC_SSTEP_N1(R) else                                                                \
     {                                                                                                                \
-        FLOWSE_PC_M1(xa, 0, 0, 0, R, 0) FLOWSE_PC_A1(ya, 0, 0, hoff, 0, 1)                                           \
-        FLOWSE_PC_M1(xa, 0, 0, 1, R, 0) FLOWSE_PC_A1(ya, 0, 1, hoff, 0, 1)                                           \
-        FLOWSE_PC_M1(xa, 0, 1, 0, R, 0) FLOWSE_PC_A1(ya, 1, 0, hoff, 0, 1)                                           \
-        FLOWSE_PC_M1(xa, 0, 1, 1, R, 0) FLOWSE_PC_A1(ya, 1, 1, hoff, 0, 1)                                           \
-        FLOWSE_PC_M1(xa, 1, 0, 0, R, 0)                                                                              \
-        FLOWSE_PC_M1(xa, 1, 0, 1, R, 0)                                                                              \
-        FLOWSE_PC_M1(xa, 1, 1, 0, R, 0) FLOWSE_PC_W1(R, 0, 0, wn0, wn1, 0)                                           \
-        FLOWSE_PC_M1(xa, 1, 1, 1, R, 0) FLOWSE_PC_W1(R, 0, 1, wn0, wn1, 0)                                           \
-        FLOWSE_PC_M1(ya, 0, 0, 0, R, 1) FLOWSE_PC_A1(xa, 0, 0, hnext, 0, 0)                                          \
-        FLOWSE_PC_M1(ya, 0, 0, 1, R, 1) FLOWSE_PC_A1(xa, 0, 1, hnext, 0, 0)                                          \
-        FLOWSE_PC_M1(ya, 0, 1, 0, R, 1) FLOWSE_PC_A1(xa, 1, 0, hnext, 0, 0)                                          \
-        FLOWSE_PC_M1(ya, 0, 1, 1, R, 1) FLOWSE_PC_A1(xa, 1, 1, hnext, 0, 0)                                          \
-        FLOWSE_PC_M1(ya, 1, 0, 0, R, 1)                                                                              \
-        FLOWSE_PC_M1(ya, 1, 0, 1, R, 1)                                                                              \
-        FLOWSE_PC_M1(ya, 1, 1, 0, R, 1) FLOWSE_PC_W1(R, 1, 0, wn0, wn1, 0)                                           \
-        FLOWSE_PC_M1(ya, 1, 1, 1, R, 1) FLOWSE_PC_W1(R, 1, 1, wn0, wn1, 0)                                           \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) {                                                          \
+            FLOWSE_PC_M1(pt, R, 0) FLOWSE_PC_A1(pt, hoff, 0, 1)                                                      \
+        }                                                                                                            \
+        FLOWSE_PC_W1(R, 0, wn0, 0)                                                                                   \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) {                                                          \
+            FLOWSE_PC_M1(pt, R, 1) FLOWSE_PC_A1(pt, hnext, 0, 0)                                                     \
+        }                                                                                                            \
+        FLOWSE_PC_W1(R, 1, wn0, 0)                                                                                   \
     }
-#define FLOWSE_PC_RESLOAD(R)                               /* residual of output round R into ring entry R (see pc16_out_hand) */ \
+#define FLOWSE_PC_RESLOAD(R)                               /* residual of output round R (= pixel tile R) into ring entry R (see pc16_out_hand) */ \
     if (tile_end && has_res) {                                                                                       \
-        _Pragma("unroll") for (int p = 0; p < 4 * NJ; ++p) {                                                         \
-            const pc_u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(                                                 \
-                po.rs_res, po.voff + (unsigned)((32 * (p >> 2) + 8 * (p & 3)) * 2), pc_osoff(po, (R) >> 1, (R) & 1), 0); \
-            FLOWSE_PC_RSET(R, p, d)                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+            const pc_u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(po.rs_res, po.voff + (unsigned)(q * 16), pc_osoff(po, (R)), 0); \
+            FLOWSE_PC_RSET(R, q, d)                                                                                  \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
@@ -574,23 +509,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
             const int64_t sb = (int64_t)pit.b * H * W * a.Cout;
             const T16* rbase = reinterpret_cast<const T16*>(has_res ? a.res : a.out) + sb;
             po.rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<T16*>(rbase), 0, H * po.rowb, 0x00020000);
-            po.voff = (unsigned)((((pit.y0 + 4 * wm + (li >> 4)) * W + pit.x0 + (li & 15)) * a.Cout + pit.n0 + wn * (32 * NJ) +
-                                  4 * kh) * 2);
+            po.voff = (unsigned)((((pit.y0 + r0 + (li >> 4)) * W + pit.x0 + (li & 15)) * a.Cout + pit.n0 + wn * 32 + 4 * kh) * 2);
         };
         set_out();
         init_acc(pit);
-        // this lane's corner of the hand-off tile: pixel (4 wm + (li >> 4), li & 15) of output round (0, 0), its first channel
-        char* const Ow = Ob + ((4 * wm + (li >> 4)) * 16 + (li & 15)) * OP + (wn * (32 * NJ) + 4 * kh) * 2;
+        // this lane's corner of the hand-off tile: pixel (r0 + (li >> 4), li & 15) = its pixel of pixel tile 0, its first channel
+        char* const Ow = Ob + ((r0 + (li >> 4)) * 16 + (li & 15)) * OP + (wn * 32 + 4 * kh) * 2;
         const bool small_k = nct < 3;                      // fewer than three chunk intervals per tile: drained at the tile's end
         int hoff = 0;                                      // byte offset of the current chunk's halo buffer
-        int nb_cur = (pit.n0 >> 5) + wn * NJ;              // this wave's first 32-channel block in the current / the next item
-        auto nb_of = [&](int k) { return ((first + k * G8) % n_ntiles) * (2 * NJ) + wn * NJ; };
+        int nb_cur = (pit.n0 >> 5) + wn;                   // this wave's 32-channel block in the current / the next item
+        auto nb_of = [&](int k) { return ((first + k * G8) % n_ntiles) * (2 * NJ) + wn; };
         int nb_next = nb_of(min(1, n_items - 1));
-        unsigned wc0, wc1, wn0, wn1;                       // scalar byte offsets: this chunk's fragments (block j = 0 / 1), the next one's
-        chunk_off(nb_cur, 0, wc0, wc1);
-        FLOWSE_PC_WLOAD(0, wc0, wc1, 0) FLOWSE_PC_WLOAD(1, wc0, wc1, 1) FLOWSE_PC_WLOAD(2, wc0, wc1, 2)
+        unsigned wc0, wn0;                                 // scalar byte offsets: this chunk's fragments, the next one's
+        chunk_off(nb_cur, 0, wc0);
+        FLOWSE_PC_WLOAD(0, wc0, 0) FLOWSE_PC_WLOAD(1, wc0, 1) FLOWSE_PC_WLOAD(2, wc0, 2)
         __syncthreads();                                   // (X 0)
-        FLOWSE_PC_LOADA(xa, 0, 0, 0)
+        FLOWSE_PC_LOADA(0)
         // One folded-shortcut chunk (ordinal S of the tile, ring entry R): its own chunk barrier, one step.  The refill of entry R
         // comes from the shortcut step three ahead (the last one again past the end: never used).
 #define FLOWSE_PC_SCHUNK(R, S)                                                                                       \
@@ -598,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         const int hnext = hoff == (PC_NHBUF - 1) * PC_HBUF_X ? 0 : hoff + PC_HBUF_X;                                 \
         __syncthreads();                                   /* (X) */                                                \
         PC_TS_ADD(1)                                                                                                 \
-        chunk_off(nb_cur, nchunks + min((S) + 3, ns - 1), wn0, wn1);                                                 \
+        chunk_off(nb_cur, nchunks + min((S) + 3, ns - 1), wn0);                                                      \
         FLOWSE_PC_SSTEP(R)                                                                                           \
         PC_TS_ADD(0)                                                                                                 \
         hoff = hnext;                                                                                                \
@@ -609,9 +543,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
                 const int hnext = hoff == (PC_NHBUF - 1) * PC_HBUF_X ? 0 : hoff + PC_HBUF_X;
                 if (gc > 0) __syncthreads();               // (X gc) the halos of chunks gc and gc + 1 are in LDS; the producers may
                 PC_TS_ADD(1)                               //        overwrite the buffer of chunk gc - 1.   1: chunk barrier
-                chunk_off(nb_cur, cit, wc0, wc1);
-                if (!tile_end || ns) chunk_off(nb_cur, cit + 1, wn0, wn1);     // (cit + 1 = nchunks: the shortcut's first steps)
-                else chunk_off(nb_next, 0, wn0, wn1);
+                chunk_off(nb_cur, cit, wc0);
+                if (!tile_end || ns) chunk_off(nb_cur, cit + 1, wn0);          // (cit + 1 = nchunks: the shortcut's first steps)
+                else chunk_off(nb_next, 0, wn0);
                 FLOWSE_PC_STEP(0) FLOWSE_PC_STEP(1) FLOWSE_PC_STEP(2) FLOWSE_PC_STEP(3) FLOWSE_PC_STEP(4) FLOWSE_PC_STEP(5)
                 FLOWSE_PC_STEP(6) FLOWSE_PC_RESLOAD(0) FLOWSE_PC_STEP(7) FLOWSE_PC_RESLOAD(1) FLOWSE_PC_STEP(8) FLOWSE_PC_RESLOAD(2)
                 PC_TS_ADD(0)                               // 0: fragments + MFMA issue
@@ -632,8 +566,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
                 }
                 // the tile is complete: rounded values into the hand-off tile (the producers drain it under the next tile's first
                 // chunks: the next chunk barrier publishes it, and they are done before this wave writes it again), next tile
-                if (has_res) pc16_out_hand<T16, true, NJ>(a, acc, Ow, wb, po);
-                else pc16_out_hand<T16, false, NJ>(a, acc, Ow, wb, po);
+                if (has_res) pc16_out_hand<T16, true, PT>(a, acc, Ow, wb, po);
+                else pc16_out_hand<T16, false, PT>(a, acc, Ow, wb, po);
                 if (small_k) {                             // (launch-uniform) no interval to drain under: the producers drain here
                     __syncthreads();
                     __syncthreads();
@@ -645,12 +579,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
                 nb_next = nb_of(min(kitem + 1, n_items - 1));
                 set_out();
                 init_acc(pit);
-                PC_TS_ADD(3)                               // 3: output stage
+                PC_TS_ADD(3)                               // 3: hand-off + the next tile's set-up
                 if (has_res || ns) {                       // (else the ring still holds the refills of taps 6-8: the next tile's
-                    chunk_off(nb_cur, 0, wc0, wc1);        //  steps 0-2)
-                    FLOWSE_PC_WLOAD(0, wc0, wc1, 0) FLOWSE_PC_WLOAD(1, wc0, wc1, 1) FLOWSE_PC_WLOAD(2, wc0, wc1, 2)
+                    chunk_off(nb_cur, 0, wc0);             //  steps 0-2)
+                    FLOWSE_PC_WLOAD(0, wc0, 0) FLOWSE_PC_WLOAD(1, wc0, 1) FLOWSE_PC_WLOAD(2, wc0, 2)
                 }
-                FLOWSE_PC_LOADA(xa, hoff, 0, 0)            // (in LDS since the barrier of the finished chunk; a stale read after the last tile is never used)
+                FLOWSE_PC_LOADA(hoff)                      // (in LDS since the barrier of the finished chunk; a stale read after the last tile is never used)
             }
         }
 #undef FLOWSE_PC_SCHUNK
@@ -662,11 +596,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
         if (wave == 0) { PC_TS_FLUSH(0) }                  // slots 0-7 of the block
 #undef FLOWSE_PC_RESLOAD
 #undef FLOWSE_PC_SSTEP
-#undef FLOWSE_PC_SSTEP_N1
-#undef FLOWSE_PC_STEP_N1
 #undef FLOWSE_PC_STEP
-#undef FLOWSE_PC_NEXTA
-#undef FLOWSE_PC_REFILL
 #undef FLOWSE_PC_M1
 #undef FLOWSE_PC_W1
 #undef FLOWSE_PC_A1
