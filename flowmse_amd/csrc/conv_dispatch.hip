@@ -80,6 +80,7 @@ int f43_plan(int B, int H, int W, int Cin, int Cout, int taps) {
 int conv_ksplit(int B, int H, int W, int Cin, int Cout, int taps) {
     if (conv_supports_head4(B, H, W, Cin, 0, Cout, taps)) return 1;     // 4-channel heads: dedicated kernel
     if (conv_smallm_ok(B, H, W, Cin, 0, Cout, taps)) return 1;          // K is split inside the block
+    if (conv_w2d_enabled() && conv_supports_w2d(B, H, W, Cin, 0, Cout, taps)) return 1;   // whole K on the 2-D Winograd kernel
     const int64_t M = (int64_t)B * H * W;
     const int bn = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;       // N tile launch_conv picks for this width
     const int bm = conv_small_m(M, Cout) ? 32 : 128;              // M tile (single utterances at the 8x8 / 4x4 levels: 32 rows)

@@ -84,6 +84,8 @@ if __name__ == "__main__":
           " (op-level entry); kernel-only times: rocprofv3 --kernel-trace --stats")
     only = int(sys.argv[sys.argv.index("--only") + 1]) if "--only" in sys.argv else None
     forms = (sys.argv[sys.argv.index("--form") + 1],) if "--form" in sys.argv else ("f43", "w2d")
+    if "--shape" in sys.argv:                                  # B,H,W,C1,C2,Cout
+        SHAPES = [tuple(int(v) for v in sys.argv[sys.argv.index("--shape") + 1].split(","))]
     for k, s in enumerate(SHAPES):
         if only is None or k == only:
             run(s, it, "--gn" in sys.argv, forms)
