@@ -156,8 +156,8 @@ def test_resblock_split_k_shapes_vs_oracle(tag, shp):
     """ResnetBlocks on images so small that every conv runs split over K (flat slices at 8x8 / 4x4, F(4,3) slices at
     16x16; 32-row tiles for a single utterance) with the two-pass reduction -- incl. the shortcut-free merged forms and
     the reduction fused with GroupNorm_1 -- against the oracle.  Since round 5 these shapes run the in-block split-K kernels
-    (conv_smallm.hip), since round 6 with GroupNorm_1 + SiLU taken from Conv_0's partial statistics inside Conv_1 (no gn_norm
-    launch): b8_16 = 2048 pixels on 64-channel tiles, b32_4 = two samples per 32-pixel tile, b1_32 = 32 partial blocks per sample."""
+    (conv_smallm.hip): b8_16 = 2048 pixels on 64-channel tiles, b32_4 = two samples per 32-pixel tile (512 pixels of 4 x 4
+    images), b1_32 = one utterance at 32 x 32 (32 statistics blocks per sample)."""
     import _gpu as G
     from oracle import ncsnpp_oracle as O
     keys = C.resblock_keys(256, 256, 512, None)
