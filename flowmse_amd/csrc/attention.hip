@@ -110,7 +110,9 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const float* 
         const int krow = k0 + li;
         // (a key row past L reads row 0: its scores are masked to -inf below, its probabilities are exactly 0, so neither the K
         // nor the V operand needs a select -- a select on a loaded value pins the wait for that load to the spot where it was
-        // issued, which is what had kept every one of these requests from running ahead: PV 31 us, S 10 us of 57)
+        // issued, which is what had kept every one of these requests from running ahead: PV 31 us, S 10 us of 57.
+        // Precondition: V row 0 finite, as for every key -- 0 x inf would be NaN; but row 0 is a real key of EVERY query, so a
+        // non-finite V[0] poisons all outputs through its own strictly positive probability with or without this shortcut.)
         const float* kp = base + (int64_t)(krow < L ? krow : 0) * rs + C + kh * 4;
         const float* qp = Qs + li * QROW + kh * 4;
         // The loop is one chain of dependent MFMAs, so a load inside it is a full memory round trip that nothing hides, and
@@ -196,7 +198,9 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const float* 
 template <int NCT>
 static int launch_att(const float* qkv, int B, int L, float* out, hipStream_t s) {
     constexpr int C = 32 * NCT;
-    const size_t lds = (ATT_SLOTS * 32 * (C + 4) + 2 * ATT_WAVES * 32) * sizeof(float);
+    constexpr size_t lds = (ATT_SLOTS * 32 * (C + 4) + 2 * ATT_WAVES * 32) * sizeof(float);
+    // one block per CU: the four merge tiles need 135 KB at C = 256 -- gfx950's 160 KB of LDS, nothing smaller
+    static_assert(lds <= 160 * 1024, "attention: the ATT_SLOTS merge tiles must fit the 160 KB of LDS of a gfx950 CU");
     if (const int rc = allow_lds<&attention_kernel<NCT>>(lds)) return rc;
     const dim3 grid((L + 31) / 32, B), block(64 * ATT_WAVES);
     hipLaunchKernelGGL(attention_kernel<NCT>, grid, block, lds, s, qkv, L, out, 1.0f / sqrtf((float)C));
@@ -349,7 +353,8 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention16_kernel(const ST* _
 template <int NCT, class ST>
 static int launch_att16(const void* qkv, int B, int L, void* out, hipStream_t s) {
     constexpr int C = 32 * NCT;
-    const size_t lds = (ATT_SLOTS * 32 * (C + 4) + 2 * ATT_WAVES * 32) * sizeof(float);      // the fp32 O tiles are the larger overlay
+    constexpr size_t lds = (ATT_SLOTS * 32 * (C + 4) + 2 * ATT_WAVES * 32) * sizeof(float);  // the fp32 O tiles are the larger overlay
+    static_assert(lds <= 160 * 1024, "attention16: the ATT_SLOTS merge tiles must fit the 160 KB of LDS of a gfx950 CU");
     if (const int rc = allow_lds<&attention16_kernel<NCT, ST>>(lds)) return rc;
     const dim3 grid((L + 31) / 32, B), block(64 * ATT_WAVES);
     hipLaunchKernelGGL((attention16_kernel<NCT, ST>), grid, block, lds, s, static_cast<const ST*>(qkv), L, static_cast<ST*>(out),

@@ -200,8 +200,8 @@ __global__ __launch_bounds__(512, 2) void conv_smallm_kernel(ConvArgs a) {
     __syncthreads();
     const int PB = HW < SM_BM ? HW : SM_BM;
     const int groups = SM_BM / PB;
-    if (tid < groups * BN) {
-        const int g = tid / BN, c = tid - g * BN;
+    for (int idx = tid; idx < groups * BN; idx += 512) {      // (H W < 4: more (block, channel) pairs than threads)
+        const int g = idx / BN, c = idx - g * BN;
         const int mg = m0 + g * PB;
         if (mg < M) {
             float sum = 0.f;

@@ -636,9 +636,24 @@ int w2d_tiles_per_block(int B, int H, int W, int Cin, int Cout) {
 }
 
 int launch_w2d(const ConvArgs& a, hipStream_t s) {
+    // the launcher checks its own preconditions (launch_conv's ordering is not a contract)
+    if (!a.wino2 || a.in_dt != DT_F32 || a.out_dt != DT_F32 || a.ksplit > 1 || a.partial || a.partial2 || a.sc1 ||
+        !conv_w2d_shape_ok(a.B, a.H, a.W, a.C1, a.C2, a.Cout, a.taps)) {
+        set_error("conv_w2d: fp32 in / out, whole K, two-dimensional Winograd weights (ConvArgs::wino2), 16 x 16-pixel tiles, "
+                  "channel counts in multiples of 32 (Cout: 64)");
+        return ERR_ARG;
+    }
+    if (a.stats && a.stats_nblk != a.H * a.W / 64) {
+        set_error("conv_w2d: statistics come in blocks of 64 pixels (stats_nblk=%d, H W / 64 = %d)", a.stats_nblk, a.H * a.W / 64);
+        return ERR_ARG;
+    }
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int nj = w2d_channel_tiles(a.B, a.H, a.W, a.Cout);
     const int tpb = w2d_tiles_per_block(a.B, a.H, a.W, a.C1 + a.C2, a.Cout);
+    if (tpb < 1 || ((int64_t)a.H * a.W / 256) % tpb != 0 || (tpb > 1 && (((a.C1 + a.C2) / KC) & 1))) {
+        set_error("conv_w2d: internal: %d tiles per block do not divide the image's tiles / need an even chunk count", tpb);
+        return ERR_STATE;
+    }
     const int grid = (int)(M / 256 / tpb) * (a.Cout / (32 * nj));
     const size_t lds = (W2_HBUF + 8 * W2_XDEST) * sizeof(float);       // halo buffer 0 + the exchange region (> two halo buffers)
     const int gn = a.gn.mean ? (a.gn_silu ? 2 : 1) : 0;

@@ -102,31 +102,28 @@ __device__ __forceinline__ void gn_group_stats(const float* __restrict__ p1, int
         if (nch <= 0 || !p) continue;
         const float2* q = reinterpret_cast<const float2*>(p) + (int64_t)b * nblk * Cs + lo;
         const int items = nblk * nch;
-        // four independent requests per round (a thread's items are summed in the same order as one at a time: the loop
-        // was a chain of ~1 us dependent latencies -- 16 rounds for the 1024 strip partials of a 256 x 256 sample)
-        int it = tid;
-        for (; it + 768 < items; it += 1024) {
-            int blk[4];
-            float2 v[4];
+        // EIGHT independent requests per round, predicated on clamped addresses (a thread's items are summed in the same order
+        // as one at a time).  The loop is a chain of ~1 us dependent round trips: one request per round took 16 rounds for the
+        // 1024 strip partials of a 256 x 256 sample, four per round (rounds 4-5) four rounds plus up to three single-request
+        // rounds for the remainder (two at 64 x 64: 512 items); now two rounds at 256 x 256 and one everywhere else.
+        for (int it = tid; it < items; it += 2048) {
+            int blk[8];
+            float2 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int k = it + 256 * u;
-                blk[u] = k / nch;
-                v[u] = q[(int64_t)blk[u] * Cs + (k - blk[u] * nch)];
+                const int kc = k < items ? k : items - 1;
+                blk[u] = kc / nch;
+                v[u] = q[(int64_t)blk[u] * Cs + (kc - blk[u] * nch)];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double n = (double)min(ppb, HW - blk[u] * ppb), m = (double)v[u].x;
-                s1 += n * m;
-                s2 += (double)v[u].y + n * m * m;
+            for (int u = 0; u < 8; ++u) {
+                if (it + 256 * u < items) {
+                    const double n = (double)min(ppb, HW - blk[u] * ppb), m = (double)v[u].x;
+                    s1 += n * m;
+                    s2 += (double)v[u].y + n * m * m;
+                }
             }
-        }
-        for (; it < items; it += 256) {
-            const int blk = it / nch, j = it - blk * nch;
-            const float2 v = q[(int64_t)blk * Cs + j];
-            const double n = (double)min(ppb, HW - blk * ppb), m = (double)v.x;
-            s1 += n * m;
-            s2 += (double)v.y + n * m * m;
         }
     }
 #pragma unroll

@@ -43,10 +43,11 @@ def batches_by_length(indices, lengths, max_batch):
 
 
 # Cost model of one sampler call on a batch of b utterances padded to T frames: T * (COST_ALPHA + COST_BETA * b).
-# Fitted to the round-3 MI355X measurements of the N=5 fp32 sampler ([1,1,256,256]: 8.85 k frames/s, [8,1,256,256]:
-# 17.9 k frames/s => 113 us / frame at b = 1, 56 us / frame / utterance at b = 8).  Only RATIOS matter: the planner uses
-# it to decide whether padding a straggler up to a longer batch is cheaper than running it in an under-filled one.
-COST_ALPHA, COST_BETA = 65.0, 48.0
+# Fitted to the round-6 MI355X measurements of the N=5 fp32 sampler ([1,1,256,256]: 11.3 k frames/s, [8,1,256,256]:
+# 21.8 k frames/s => 88 us / frame at b = 1, 46 us / frame / utterance at b = 8; round 3's fit was 65 / 48).  Only the RATIO
+# matters (1.35 -> 1.2: a batch slot costs relatively more than it did): the planner uses it to cut the length-sorted set into
+# batches and to decide whether padding a straggler up to a longer batch is cheaper than running it in an under-filled one.
+COST_ALPHA, COST_BETA = 48.0, 40.0
 
 
 def batch_cost(T, b):
@@ -169,30 +170,48 @@ def _pad_to(t, multiple):
 # from an earlier call references its storage any more (torch's storage use count) -- a caller that keeps two result
 # sets alive simply owns two buffers.
 _STAGE_POOL = []
+_STAGE_POOL_MAX = 2                                                # unreferenced buffers kept for reuse (a live result set owns its own)
 _SIDE_STREAMS = {}                                                 # device index -> the drain's copy stream
 
 
-def _storage_free(buf):
+def _use_count(buf):
+    """References to the storage of `buf` (torch's storage use count), or None where this build of torch has no such query."""
+    fn = getattr(torch._C, "_storage_Use_Count", None)
+    if fn is None:
+        return None
     try:
-        return torch._C._storage_Use_Count(buf.untyped_storage()._cdata) <= 2      # `buf` itself + the temporary
-    except Exception:                                                                # API moved: never alias, allocate
-        return False
+        return int(fn(buf.untyped_storage()._cdata))
+    except Exception:
+        return None
 
 
-def _acquire_stage(nfloats):
-    """A pinned fp32 buffer of >= nfloats elements that no live tensor views; grown (not shrunk) on demand."""
-    best = None
-    for k, buf in enumerate(_STAGE_POOL):
-        if _storage_free(buf) and (best is None or buf.numel() > _STAGE_POOL[best].numel()):
-            best = k
-    if best is not None and _STAGE_POOL[best].numel() >= nfloats:
-        return _STAGE_POOL[best]
-    if best is not None:
-        del _STAGE_POOL[best]                                      # too small and unreferenced: replace it
+def _storage_free(buf):
+    n = _use_count(buf)
+    return n is not None and n <= 2                                # `buf` itself + the temporary
+
+
+def _new_stage(nfloats):
     buf = torch.empty(max(int(nfloats * 1.125), 1), dtype=torch.float32)
     if torch.cuda.is_available():                                  # (plain memory in the CPU-only unit test)
         buf = buf.pin_memory()
-    _STAGE_POOL.append(buf)
+    return buf
+
+
+def _acquire_stage(nfloats):
+    """A pinned fp32 buffer of >= nfloats elements that no live tensor views; grown (not shrunk) on demand.  The pool keeps
+    at most _STAGE_POOL_MAX unreferenced buffers (the largest ones); where the use count cannot be queried nothing is pooled
+    at all -- a fresh buffer per call is slow (it is page-locked each time) but can never alias a result."""
+    if _use_count(torch.empty(1)) is None:
+        return _new_stage(nfloats)
+    free = sorted((k for k, buf in enumerate(_STAGE_POOL) if _storage_free(buf)), key=lambda k: -_STAGE_POOL[k].numel())
+    hit = next((k for k in free if _STAGE_POOL[k].numel() >= nfloats), None)
+    keep = set(free[:_STAGE_POOL_MAX]) | ({hit} if hit is not None else set())
+    if hit is None and free:
+        keep.discard(free[0])                                      # too small and unreferenced: replaced below
+    buf = _STAGE_POOL[hit] if hit is not None else _new_stage(nfloats)
+    _STAGE_POOL[:] = [b for k, b in enumerate(_STAGE_POOL) if k in keep or not _storage_free(b)]
+    if hit is None:
+        _STAGE_POOL.append(buf)
     return buf
 
 

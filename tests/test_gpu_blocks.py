@@ -124,6 +124,33 @@ def test_resblock_16bit_storage_vs_oracle(tag, cin, cout, shp, kw, split, mode, 
     assert got.shape == ref.shape and err < bound
 
 
+def test_resblock_16bit_shortcut_fold_safety_net():
+    """The 1x1 shortcut is folded into Conv_1's launch from PREDICTED shapes (the shortcut launch is skipped before Conv_0
+    exists); if the Conv_1 that is finally planned does not take the fold, the shortcut must run late as its own launch and
+    ride as the residual (FLOWSE_SCFOLD_LATE=1 forces that branch): same result as the folded plan, within the mode's ceiling."""
+    import os
+    import _gpu as G
+    from oracle import ncsnpp_oracle as O
+    tag, cin, cout, shp, kw, split = [c for c in CASES16 if c[0] == "concat_halo_shortcut"][0]
+    keys = C.resblock_keys(cin, cout, 512, None)
+    wl = _weights(keys, f"b16.{tag}.")
+    x = torch.from_numpy(synth.normal(7, 11, shp))
+    temb = torch.from_numpy(synth.normal(7, 12, (shp[0], 512)))
+    ref = O.resblock(O._W({f"all_modules.0.{k}": v for k, v in wl.items()}), 0, x, temb)
+    outs = {}
+    for late in (False, True):
+        if late:
+            os.environ["FLOWSE_SCFOLD_LATE"] = "1"
+        try:
+            blk = G.Block("resnet", cin, cout, temb_dim=512).load(wl, precision="bf16")
+            outs[late] = blk(x[:, :split].contiguous(), x[:, split:].contiguous(), temb=temb)
+        finally:
+            os.environ.pop("FLOWSE_SCFOLD_LATE", None)
+    e0, e1, d = C.rel_l2(outs[False], ref), C.rel_l2(outs[True], ref), C.rel_l2(outs[True], outs[False])
+    print(f"folded {e0:.3e}  late shortcut {e1:.3e}  between them {d:.3e}")
+    assert e0 < 6e-3 and e1 < 6e-3 and 0 < d < 6e-3               # (d > 0: the late branch really ran another plan)
+
+
 @pytest.mark.parametrize("mode,bound", MODES16)
 def test_attnblock_16bit_storage_vs_oracle(mode, bound):
     import _gpu as G

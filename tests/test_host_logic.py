@@ -247,6 +247,32 @@ def test_gather_staging_buffer_is_reused_not_aliased():
     P._STAGE_POOL.clear()
 
 
+def test_gather_staging_pool_is_capped():
+    """A caller that held several result sets alive at once leaves several buffers behind: once they are unreferenced the pool
+    drops all but _STAGE_POOL_MAX of them (the largest), and without torch's storage use count nothing is pooled at all."""
+    from flowmse_amd import parallel as P
+    P._STAGE_POOL.clear()
+    held = []
+    for n in (100, 200, 300, 400):
+        buf = P._acquire_stage(n)
+        held.append(buf[:8].view(2, 4))                            # a live result per call: four buffers
+        del buf
+    assert P.stage_pool_stats()[0] == 4
+    del held
+    x = P._acquire_stage(50)
+    assert P.stage_pool_stats()[0] <= P._STAGE_POOL_MAX and x.numel() >= 400      # the largest one serves, the rest is gone
+    del x
+    saved = getattr(torch._C, "_storage_Use_Count")
+    try:
+        del torch._C._storage_Use_Count                            # "the private API moved"
+        n0 = P.stage_pool_stats()[0]
+        y, z = P._acquire_stage(10), P._acquire_stage(10)
+        assert y is not z and P.stage_pool_stats()[0] == n0        # fresh buffers, never pooled
+    finally:
+        torch._C._storage_Use_Count = saved
+    P._STAGE_POOL.clear()
+
+
 def test_fused_sampler_only_for_classes_that_opt_in_themselves():
     """A plugin that subclasses a built-in solver and overrides update_fn must go through the plugin loop (its update_fn
     is what runs); only the built-in classes themselves map to the library's fused loop."""

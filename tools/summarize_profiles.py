@@ -113,35 +113,38 @@ def main(tag):
         print("wrote", os.path.join(P, f"{tag}_pmc_dominant_kernel.txt"))
     sq16 = os.path.join(G, "prof_sq16", f"{tag}_counter_collection.csv")
     if os.path.exists(sq16):                                # SQ counters of the 16-bit producer / consumer conv (bf16 run)
-        vals, durs, name = collections.defaultdict(list), [], None
+        # PER INSTANTIATION (round 5 blended <2, false, 2> with <2, false, 1>: 128- and 64-channel blocks are different kernels)
+        vals, durs = collections.defaultdict(lambda: collections.defaultdict(list)), collections.defaultdict(list)
         with open(sq16) as f:
             for r in csv.DictReader(f):
-                if "conv3x3_pc16_kernel<2" in r["Kernel_Name"]:
+                if "conv3x3_pc16_kernel<" in r["Kernel_Name"]:
                     name = r["Kernel_Name"][:120]
-                    vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
                     if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
-                        durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                        durs[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         if durs:
-            m = {k: sum(v) / len(v) for k, v in vals.items()}
-            dur = sum(durs) / len(durs)
-            cyc = m["GRBM_GUI_ACTIVE"] / 8.0
             with open(os.path.join(P, f"{tag}_pmc_bf16_kernel.txt"), "w") as f:
                 f.write("# rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
                         "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- python bench.py --steps 1 --warmup 1 "
-                        "--precision bf16 --no-cpu-baseline --no-alt\n")
-                f.write(f"# kernel: {name}, {len(durs)} launches (all its shapes at [8,1,256,256], N=5), avg {dur / 1e3:.1f} us "
-                        "(profiled run)\n")
-                for k in sorted(m):
-                    f.write(f"{k:28s} per launch {m[k]:.4e}\n")
-                f.write(f"effective clock (GRBM_GUI_ACTIVE / 8 XCD / duration): {cyc / dur:.2f} GHz\n")
-                f.write("MFMA busy fraction per SIMD (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMD x cycles)): "
-                        f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.3f}\n")
-                if "SQ_BUSY_CU_CYCLES" in m:
-                    cu = m["SQ_BUSY_CU_CYCLES"] / 256.0
-                    f.write(f"shader clock from the CUs' own busy cycles (SQ_BUSY_CU_CYCLES / 256 CUs / duration): {cu / dur:.2f} GHz; "
-                            f"MFMA busy fraction per SIMD at that clock: {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cu):.3f}\n"
-                            "# (s_memtime inside the kernel agrees with the second clock: 1.4-1.7 GHz against the 100 MHz counter, "
-                            "tools/pc16_ts.py -- the part clocks this kernel down; GRBM_GUI_ACTIVE does not follow it)\n")
+                        "--precision bf16 --no-cpu-baseline --no-alt\n"
+                        "# one block per template instantiation <GN, F16, NJ> (NJ = 2: 128-channel blocks, 1: 64-channel blocks)\n")
+                for name in sorted(durs, key=lambda k: -sum(durs[k])):
+                    m = {k: sum(v) / len(v) for k, v in vals[name].items()}
+                    dur = sum(durs[name]) / len(durs[name])
+                    cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+                    f.write(f"\n# kernel: {name}, {len(durs[name])} launches (its shapes at [8,1,256,256], N=5), avg {dur / 1e3:.1f} us "
+                            "(profiled run)\n")
+                    for k in sorted(m):
+                        f.write(f"{k:28s} per launch {m[k]:.4e}\n")
+                    f.write(f"effective clock (GRBM_GUI_ACTIVE / 8 XCD / duration): {cyc / dur:.2f} GHz\n")
+                    f.write("MFMA busy fraction per SIMD (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMD x cycles)): "
+                            f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.3f}\n")
+                    if "SQ_BUSY_CU_CYCLES" in m:
+                        cu = m["SQ_BUSY_CU_CYCLES"] / 256.0
+                        f.write(f"shader clock from the CUs' own busy cycles (SQ_BUSY_CU_CYCLES / 256 CUs / duration): {cu / dur:.2f} GHz; "
+                                f"MFMA busy fraction per SIMD at that clock: {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cu):.3f}\n")
+                f.write("# (s_memtime inside the kernel agrees with the second clock: 1.3-1.7 GHz against the 100 MHz counter, "
+                        "tools/pc16_ts.py -- the part clocks this kernel down; GRBM_GUI_ACTIVE does not follow it)\n")
             print("wrote", os.path.join(P, f"{tag}_pmc_bf16_kernel.txt"))
     for k in dom:
         print(k, out[k])
