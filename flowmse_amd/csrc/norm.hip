@@ -102,28 +102,51 @@ __device__ __forceinline__ void gn_group_stats(const float* __restrict__ p1, int
         if (nch <= 0 || !p) continue;
         const float2* q = reinterpret_cast<const float2*>(p) + (int64_t)b * nblk * Cs + lo;
         const int items = nblk * nch;
-        // EIGHT independent requests per round, predicated on clamped addresses (a thread's items are summed in the same order
-        // as one at a time).  The loop is a chain of ~1 us dependent round trips: one request per round took 16 rounds for the
-        // 1024 strip partials of a 256 x 256 sample, four per round (rounds 4-5) four rounds plus up to three single-request
-        // rounds for the remainder (two at 64 x 64: 512 items); now two rounds at 256 x 256 and one everywhere else.
-        for (int it = tid; it < items; it += 2048) {
-            int blk[8];
-            float2 v[8];
+        // four independent requests per round (a thread's items are summed in the same order as one at a time: the loop
+        // was a chain of ~1 us dependent latencies -- 16 rounds for the 1024 strip partials of a 256 x 256 sample); a remainder
+        // of two or three items per thread is ONE predicated round on clamped addresses (round 5 took them one per round: two
+        // extra round trips at 64 x 64), a single item stays a single request (eight predicated requests for everything, tried
+        // in round 6, cost the single-utterance shape 1.2 %: most of its launches hold one item per thread)
+        int it = tid;
+        for (; it + 768 < items; it += 1024) {
+            int blk[4];
+            float2 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int k = it + 256 * u;
-                const int kc = k < items ? k : items - 1;
+                blk[u] = k / nch;
+                v[u] = q[(int64_t)blk[u] * Cs + (k - blk[u] * nch)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double n = (double)min(ppb, HW - blk[u] * ppb), m = (double)v[u].x;
+                s1 += n * m;
+                s2 += (double)v[u].y + n * m * m;
+            }
+        }
+        if (it + 256 < items) {                              // two or three left
+            int blk[3];
+            float2 v[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int k = it + 256 * u, kc = k < items ? k : items - 1;
                 blk[u] = kc / nch;
                 v[u] = q[(int64_t)blk[u] * Cs + (kc - blk[u] * nch)];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 3; ++u) {
                 if (it + 256 * u < items) {
                     const double n = (double)min(ppb, HW - blk[u] * ppb), m = (double)v[u].x;
                     s1 += n * m;
                     s2 += (double)v[u].y + n * m * m;
                 }
             }
+        } else if (it < items) {
+            const int blk = it / nch, j = it - blk * nch;
+            const float2 v = q[(int64_t)blk * Cs + j];
+            const double n = (double)min(ppb, HW - blk * ppb), m = (double)v.x;
+            s1 += n * m;
+            s2 += (double)v.y + n * m * m;
         }
     }
 #pragma unroll
