@@ -4,6 +4,23 @@
 // contract as conv_f43.hip, evaluated in the TWO-dimensional Winograd form F(4,3) (vertical) x F(2,3) (horizontal).
 #include "conv_common.h"
 
+#ifdef FLOWSE_MEASURE_W2D
+// measurement build only (tools/w2d_ts.py): 100 MHz time stamps of block 0 .. 255, wave 0: [block][64] slots
+namespace flowse { __device__ unsigned long long g_w2d_ts[256 * 64]; }
+extern "C" int flowse_debug_w2d_ts(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(flowse::g_w2d_ts), (size_t)n * 8) == hipSuccess ? 0 : 1;
+}
+#ifdef FLOWSE_MEASURE_W2D_WAVES
+/* per-wave arrival at the slot barrier of slots 0..7: [block][wave 8][slot 8]; slot 0 of wave w also holds nothing else */
+#define W2_TS(K) if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && (K) >= 4 && ((K) - 4) % 3 == 0 && ((K) - 4) / 3 < 8) \
+        flowse::g_w2d_ts[blockIdx.x * 64 + (threadIdx.x >> 6) * 8 + ((K) - 4) / 3] = __builtin_amdgcn_s_memrealtime();
+#else
+#define W2_TS(K) if (threadIdx.x == 0 && blockIdx.x < 256 && (K) < 64) flowse::g_w2d_ts[blockIdx.x * 64 + (K)] = __builtin_amdgcn_s_memrealtime();
+#endif
+#else
+#define W2_TS(K)
+#endif
+
 namespace flowse {
 
 // ---------------------------------------------------------------------------------------------------
@@ -209,6 +226,7 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
     float* Hs = smem;                                    // [2][18][W2_HROW]
 
     const int tid = threadIdx.x;
+    W2_TS(0)
     const int H = a.H, W = a.W, HW = H * W;
     const int C1 = a.C1, C2 = a.C2, Cin = C1 + C2;
     const int n_ntiles = a.Cout / BN;
@@ -354,6 +372,7 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
         }
     }
     __syncthreads();
+    W2_TS(1)
 
 #define W2_FENCE __builtin_amdgcn_sched_barrier(0);
     // (the four base registers INCLUDE the offset of the buffer being read and are flipped at the slot barrier: every
@@ -499,7 +518,9 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
         W2_PHASE(dA, dB, 3, wb, { xform1(3); xform1(4); })
         xform1(5);
         lstoreH(1);
+        W2_TS(4 + 3 * slot)
         __syncthreads();                                 // slot + 1's halo is complete; nobody reads this slot's any more
+        W2_TS(5 + 3 * slot)
         aA0 += dflip; aA1 += dflip; aB0 += dflip; aB1 += dflip;
         s_st -= dflip;
         dflip = -dflip;
@@ -507,9 +528,11 @@ __device__ __forceinline__ void conv3x3_w2d_body(const ConvArgs& a, float* smem,
         // phase 3: slot + 1's k-block 0 from the other buffer; slot + 2's first half is requested
         stage_advance();
         W2_PHASE(dB, dA, 0, wbn, { gloadH(stg, sg_c, 0); })
+        W2_TS(6 + 3 * slot)
         if (last) {
             const bool more = ti + 1 < tpb;
             w2d_out<CH, NJ>(acc, smem + W2_HBUF, b, cur_y0, cur_x0, n0);
+            W2_TS(2 + (ti & 1))
             if (!more) return;
             __syncthreads();                             // buffer 1 (under the exchange region) is written again in the next tile
             // (the operands phase 3 fetched for the next tile were not kept across the output stage: 36 registers.  Requesting
