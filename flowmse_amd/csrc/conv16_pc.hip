@@ -371,12 +371,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
 
     if (wave < 4) {
         // ====================================================== consumers: A fragments from LDS, B fragments from L2, MFMA
-        // their share of the prologue: chunks 1 and 2 -> buffers 1 and 2 (the producers: chunk 0, the requests of chunks 3, 4)
+        // their share of the prologue: chunk 1 -> buffer 1 (the producers: chunk 0, the requests of chunks 2 and 3).  Rounds 5 /
+        // 6a had them stage chunk 2 as well: two normalisation bursts (~5.4 k cycles) in front of the first MFMA of every launch;
+        // chunk 2 is only needed at the SECOND chunk barrier and the producers are idle during chunk 0 (all buffers full)
         rq_next();
         FLOWSE_PC_HLOAD(ra, hin_a, pa)
-        FLOWSE_PC_HLOAD(rb, hin_b, pb)
         FLOWSE_PC_BURST(ra, hin_a, pa, PC_HBUF_X)
-        FLOWSE_PC_BURST(rb, hin_b, pb, 2 * PC_HBUF_X)
         const int lane = tid & 63;
         const int wm = wave >> 1, wn = wave & 1;
         const int li = lane & 31, kh = lane >> 5;
@@ -676,13 +676,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     }
 
     // =================================================================================== producers: halo staging + drain
-    // ---- prologue: chunk 0 -> buffer 0 (chunks 1 and 2: the consumer waves, above); raw pieces of chunks 3 and 4 in flight
+    // ---- prologue: chunk 0 -> buffer 0 (chunk 1: the consumer waves, above); raw pieces of chunks 2 and 3 in flight
     FLOWSE_PC_HLOAD(ra, hin_a, pa)
-    rq_next();                                             // (chunks 1, 2)
-    rq_next();
-    FLOWSE_PC_HLOAD(rb, hin_b, pb)
+    rq_next();                                             // (chunk 1)
+    FLOWSE_PC_HLOAD(rb, hin_b, pb)                         // chunk 2
     FLOWSE_PC_BURST(ra, hin_a, pa, 0)
-    FLOWSE_PC_HLOAD(ra, hin_a, pa)
+    FLOWSE_PC_HLOAD(ra, hin_a, pa)                         // chunk 3
     PC_TS_DECL
     PC_TS_START
     // ---- drain of the hand-off tile O (written by the consumers at the end of a tile, published by the next chunk barrier):
@@ -778,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
     const bool small_k = nct < 3;                          // fewer than three chunk intervals per tile: drained at the tile's end
     int cit = 0;                                           // chunk (of the tile) of the current interval
     int kt = 0;                                            // ordinal of the tile the consumers work on
-    int hb = 0;                                            // buffer (byte offset) of chunk g + 2
+    int hb = (PC_NHBUF - 1) * PC_HBUF_X;                   // buffer (byte offset) of chunk g + 2
     // One chunk interval g: after the chunk barrier the consumers work on chunk g and are done with chunk g - 1, whose buffer
     // takes chunk g + 2 (raw pieces RX, requested two intervals ago); then the raw pieces of chunk g + 4 are requested into the
     // same registers.  Three halo buffers (round 6: the fourth made room for the hand-off tile; rounds 4-5 measured three and
@@ -824,12 +823,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
             ++kt;                                                                                                    \
         }                                                                                                            \
     }
-    {
-        const int g = 0;                                   // interval 0: all three buffers hold chunks 0-2, nothing to stage
-        FLOWSE_PC_LCHUNK(false, rb, hin_b, pb)
-    }
-    for (int g = 1; g < Ctot; g += 2) {
-        FLOWSE_PC_LCHUNK(true, rb, hin_b, pb)              // rb holds chunk g + 2
+    for (int g = 0; g < Ctot; g += 2) {
+        FLOWSE_PC_LCHUNK(true, rb, hin_b, pb)              // rb holds chunk g + 2 (interval 0: chunk 2, needed at the second barrier)
         if (g + 1 < Ctot) {
             const int g1 = g + 1;
             {
