@@ -644,13 +644,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pc16_kernel(ConvArgs a) {
                 nb_cur = nb_next;
                 nb_next = nb_of(min(kitem + 1, n_items - 1));
                 set_out();
-                init_acc(pit);
-                PC_TS_ADD(3)                               // 3: output stage
+                // the next tile's first operands are requested BEFORE the biases are waited for (one memory round trip in front
+                // of the tile's first MFMA instead of two)
                 if (has_res || ns) {                       // (else the ring still holds the refills of taps 6-8: the next tile's
                     chunk_off(nb_cur, 0, wc0, wc1);        //  steps 0-2)
                     FLOWSE_PC_WLOAD(0, wc0, wc1, 0) FLOWSE_PC_WLOAD(1, wc0, wc1, 1) FLOWSE_PC_WLOAD(2, wc0, wc1, 2)
                 }
                 FLOWSE_PC_LOADA(xa, hoff, 0, 0)            // (in LDS since the barrier of the finished chunk; a stale read after the last tile is never used)
+                __builtin_amdgcn_sched_barrier(0);
+                init_acc(pit);
+                PC_TS_ADD(3)                               // 3: hand-off + the next tile's set-up
             }
         }
 #undef FLOWSE_PC_SCHUNK
