@@ -10,14 +10,17 @@
 //     through a ring of three register sets, requested three steps ahead -- and 16 MFMAs per (tap, 32-channel chunk) step.
 //     Every other instruction of a step sits in the gap behind ONE MFMA (FLOWSE_PC_STEP).  No weight tile in LDS, hence no
 //     barrier per step.
-//   * Waves 4-7 ("producers", one per SIMD) stage halos only: raw 16-byte pieces (8 channels of a pixel) requested four
-//     chunks ahead, GroupNorm + SiLU (affine folded to one FMA, v_exp / v_rcp, one rounding to the operand type) two chunks
-//     to three chunks ahead into one of FOUR halo buffers, in scalar fp32 instructions.
+//   * Waves 4-7 ("producers", one per SIMD) stage halos: raw 16-byte pieces (8 channels of a pixel) requested two chunks
+//     ahead, GroupNorm + SiLU (affine folded to one FMA, v_exp / v_rcp, one rounding to the operand type) one chunk ahead of the
+//     barrier that needs them, into one of THREE halo buffers, in scalar fp32 instructions -- and (round 6) DRAIN the finished
+//     tile: see "hand-off of a finished tile" below.
 //   * ONE barrier per chunk (X): the consumers are done with the previous chunk's buffer, the staged chunks are visible.
-//   * Output stage in the consumers (pc16_out_wide): wave-private LDS transposition tiles, 16-byte stores, residuals
-//     requested into the idle B ring during the tile's last three steps, GroupNorm partial statistics of the tensor
-//     written; its block barrier (S, for the statistics exchange between the two pixel halves) is matched by the producers.
-// LDS: 4 halo buffers [18][18 px x 80 B + 96] + statistics scratch + four transposition tiles = 146 KB.
+//   * Output stage (round 6): the MFMAs run transposed, the accumulators start at the biases, and the consumers only scale,
+//     round and write runs of four channels into a hand-off tile in LDS (pc16_out_hand); the producers store it (16-byte
+//     write-through stores) and take the GroupNorm partial statistics of what is stored during the next tile's first two
+//     chunk intervals.  Residuals are requested into the idle B ring during the tile's last three steps.  No block barrier
+//     per tile.
+// LDS: 3 halo buffers [18][18 px x 80 B + 96] + statistics scratch + the hand-off tile [256 px][64 NJ ch + 16 B] = 153 KB.
 //
 // How it got here (round 4; tools/pc16_ts.py = s_memtime accumulators per role against the 100 MHz counter, [8,.,256,256]
 // 128 -> 128 with GroupNorm + SiLU input and residual; ideal MFMA time 8 tiles x 36 steps x 512 = 147 k cycles per block):
